@@ -1,0 +1,315 @@
+"""esctp1raytracer_amd -- MI355X-native drop-in for the per-pixel render loop of
+pg42819/EscTp1RayTracer.
+
+Python here is a thin host mirror over the C ABI (include/esctp1_rt.h, libesctp1rt.so);
+all rendering happens in hand-written HIP kernels for gfx950.  Names follow the reference:
+`Scene` ~ tracer::scene (scene.h), `Scene.load_obj` ~ model::loadobj (sceneloader.h:10),
+`Camera` ~ tracer::camera (camera.h), `Renderer.render_rows` ~ the scan_row row loop
+(main.cpp:628-636), `trace` ~ ispc::trace (trace.ispc:86-92), `write_ppm` ~ main.cpp:658-689.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_LDS,
+                    ESC_STAGE_SMEM, EscError, check)
+
+__all__ = ["Scene", "Camera", "Renderer", "trace", "write_ppm", "quantise", "synthetic_view",
+           "EscError", "ESC_FACE_FIXED", "ESC_FACE_HASH", "ESC_STAGE_AUTO", "ESC_STAGE_SMEM",
+           "ESC_STAGE_LDS", "version"]
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def version():
+    return _capi.load().esc_version().decode()
+
+
+class Scene:
+    """Host scene: geometries (de-indexed triangles + one material), light list, spheres."""
+
+    def __init__(self):
+        self._lib = _capi.load()
+        self._h = self._lib.esc_scene_new()
+        if not self._h:
+            raise MemoryError("esc_scene_new")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.esc_scene_free(h)
+
+    # -- building -------------------------------------------------------------------
+    def add_geometry(self, vertex, face_index, material, normals=None):
+        v = _f32(vertex, (-1, 3))
+        f = np.ascontiguousarray(face_index, dtype=np.uint32).reshape(-1, 3)
+        m = _f32(material, (13,))
+        if normals is None or len(normals) == 0:
+            n, nn = None, 0
+        else:
+            n = _f32(normals, (-1, 3))
+            nn = n.shape[0]
+        return check(self._lib.esc_scene_add_geometry(
+            self._h, _fp(v), v.shape[0], _fp(n) if n is not None else None, nn,
+            f.ctypes.data_as(C.POINTER(C.c_uint32)), f.shape[0], _fp(m)))
+
+    def add_spheres(self, spheres_xyzr, materials):
+        s = _f32(spheres_xyzr, (-1, 4))
+        m = _f32(materials, (-1, 13))
+        if s.shape[0] != m.shape[0]:
+            raise ValueError("one material per sphere")
+        check(self._lib.esc_scene_add_spheres(self._h, _fp(s), _fp(m), s.shape[0]))
+
+    @classmethod
+    def load_obj(cls, path):
+        """model::loadobj (sceneloader.cpp:14-106)."""
+        sc = cls()
+        check(sc._lib.esc_scene_load_obj(sc._h, str(path).encode()))
+        return sc
+
+    @classmethod
+    def synthetic(cls, config, n_override=0):
+        """BASELINE.json workloads: 'c2' | 'c3' | 'c4' | 'c5' (SURVEY.md 8(d))."""
+        sc = cls()
+        check(sc._lib.esc_scene_synthetic(sc._h, config.encode(), int(n_override)))
+        return sc
+
+    # -- introspection --------------------------------------------------------------
+    def info(self):
+        i = _capi.esc_scene_info()
+        check(self._lib.esc_scene_get_info(self._h, C.byref(i)))
+        return {"n_geometry": i.n_geometry, "n_lights": i.n_lights,
+                "n_triangles": i.n_triangles, "n_spheres": i.n_spheres}
+
+    def geometry(self, g):
+        cnt = (C.c_int32 * 3)()
+        check(self._lib.esc_scene_geometry_counts(self._h, g, cnt))
+        nv, nn, nf = cnt[0], cnt[1], cnt[2]
+        v = np.zeros((nv, 3), np.float32)
+        n = np.zeros((nn, 3), np.float32)
+        f = np.zeros((nf, 3), np.uint32)
+        m = np.zeros(13, np.float32)
+        check(self._lib.esc_scene_geometry_copy(
+            self._h, g, _fp(v), _fp(n) if nn else None,
+            f.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(m)))
+        return {"vertex": v, "normals": n, "face_index": f, "material": m}
+
+    def light_sources(self):
+        n = self.info()["n_lights"]
+        out = np.zeros(max(n, 1), np.int32)
+        check(self._lib.esc_scene_light_sources(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[:n].copy()
+
+    def spheres(self):
+        n = self.info()["n_spheres"]
+        s = np.zeros((n, 4), np.float32)
+        m = np.zeros((n, 13), np.float32)
+        if n:
+            check(self._lib.esc_scene_spheres_copy(self._h, _fp(s), _fp(m)))
+        return s, m
+
+    def flatten_ispc(self, sort_by_centroid_x=False):
+        """flatten_scene_ispc (flatten_iscp.cpp:35-111) -> FlatScene."""
+        return FlatScene(self, sort_by_centroid_x)
+
+
+class FlatScene:
+    """FlatScene of flatten_iscp.h:9-13: ispc_triangle[] / ispc_light[] / light faces."""
+
+    def __init__(self, scene, sort_by_centroid_x=False):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        check(self._lib.esc_flatten_ispc(scene._h, 1 if sort_by_centroid_x else 0,
+                                         C.byref(self._h)))
+        n = C.c_int32()
+        self.triangles = self._lib.esc_flat_triangles(self._h, C.byref(n))
+        self.num_triangles = n.value
+        self.light_triangles = self._lib.esc_flat_light_triangles(self._h, C.byref(n))
+        self.num_light_triangles = n.value
+        self.lights = self._lib.esc_flat_lights(self._h, C.byref(n))
+        self.num_lights = n.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.esc_flat_free(h)
+
+
+class Camera:
+    """tracer::camera (camera.h:16-29): the four vectors get_ray needs, computed on the host."""
+
+    def __init__(self, lookfrom, lookat, vup=(0.0, 1.0, 0.0), vfov=60.0, aspect=4.0 / 3.0):
+        self.lookfrom = _f32(lookfrom, (3,))
+        self.lookat = _f32(lookat, (3,))
+        self.vup = _f32(vup, (3,))
+        self.vfov = float(np.float32(vfov))
+        self.aspect = float(np.float32(aspect))
+        self.c = _capi.esc_camera()
+        _capi.load().esc_camera_init(C.byref(self.c), _fp(self.lookfrom), _fp(self.lookat),
+                                     _fp(self.vup), self.vfov, self.aspect)
+
+    @classmethod
+    def for_image(cls, lookfrom, lookat, W, H, vup=(0.0, 1.0, 0.0), vfov=60.0):
+        # main.cpp:548  float aspect = float(image_width) / image_height;
+        return cls(lookfrom, lookat, vup, vfov, np.float32(W) / np.float32(H))
+
+    def vectors(self):
+        return {k: np.array(getattr(self.c, k), np.float32)
+                for k in ("origin", "lower_left_corner", "horizontal", "vertical")}
+
+
+def synthetic_view():
+    eye = np.zeros(3, np.float32)
+    look = np.zeros(3, np.float32)
+    _capi.load().esc_synthetic_view(_fp(eye), _fp(look))
+    return eye, look
+
+
+def _options(shadows, face_mode, fixed_face, seed, stage):
+    o = _capi.esc_render_options()
+    o.shadows = 1 if shadows else 0
+    o.face_mode = face_mode
+    o.fixed_face = fixed_face
+    o.stage = stage
+    o.seed = seed
+    return o
+
+
+class Renderer:
+    """Device context: one per GPU / host thread.  Raises EscError(ESC_ERR_NO_DEVICE) when no
+    GPU is present -- there is no CPU fallback."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        check(self._lib.esc_context_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.esc_context_destroy(h)
+
+    def set_stream(self, stream):
+        """stream: a raw hipStream_t (int) or an object with .cuda_stream (torch.cuda.Stream)."""
+        ptr = getattr(stream, "cuda_stream", stream)
+        check(self._lib.esc_context_set_stream(self._h, C.c_void_p(int(ptr))))
+
+    def stream_handle(self):
+        return self._lib.esc_context_stream(self._h)
+
+    def synchronize(self):
+        check(self._lib.esc_context_synchronize(self._h))
+
+    def upload(self, scene):
+        if isinstance(scene, FlatScene):
+            check(self._lib.esc_upload_flat(self._h, scene.num_triangles, scene.triangles,
+                                            scene.num_lights, scene.lights,
+                                            scene.num_light_triangles, scene.light_triangles))
+        else:
+            check(self._lib.esc_upload_scene(self._h, scene._h))
+
+    def render_rows(self, camera, W, H, row_begin, row_end, out_f32=None, out_u8=None, *,
+                    shadows=True, face_mode=ESC_FACE_FIXED, fixed_face=0, seed=0,
+                    stage=ESC_STAGE_AUTO):
+        """Asynchronous band render into DEVICE buffers (torch tensors or raw pointers),
+        band-local layout ((h - row_begin) * W + w) * 3."""
+        n = (row_end - row_begin) * W * 3
+
+        def ptr(buf, itemsize):
+            if buf is None:
+                return None
+            if hasattr(buf, "data_ptr"):
+                if buf.numel() * buf.element_size() < n * itemsize:
+                    raise ValueError("output buffer too small for the band")
+                if not buf.is_cuda or not buf.is_contiguous():
+                    raise ValueError("output must be a contiguous device tensor")
+                return C.c_void_p(buf.data_ptr())
+            return C.c_void_p(int(buf))
+
+        o = _options(shadows, face_mode, fixed_face, seed, stage)
+        check(self._lib.esc_render_rows(self._h, C.byref(camera.c), W, H, row_begin, row_end,
+                                        C.byref(o), ptr(out_f32, 4), ptr(out_u8, 1)))
+
+    def render(self, camera, W, H, *, want_u8=False, shadows=True, face_mode=ESC_FACE_FIXED,
+               fixed_face=0, seed=0, stage=ESC_STAGE_AUTO):
+        """Whole frame into host numpy arrays (synchronous): fp32 (H, W, 3), h = 0 bottom row,
+        and optionally the PPM-quantised bytes."""
+        img = np.zeros((H, W, 3), np.float32)
+        u8 = np.zeros((H, W, 3), np.uint8) if want_u8 else None
+        o = _options(shadows, face_mode, fixed_face, seed, stage)
+        check(self._lib.esc_render_frame_host(
+            self._h, C.byref(camera.c), W, H, C.byref(o), _fp(img),
+            u8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_u8 else None))
+        return (img, u8) if want_u8 else img
+
+    def reset_counters(self):
+        check(self._lib.esc_reset_counters(self._h))
+
+    def counters(self):
+        c = _capi.esc_counters()
+        check(self._lib.esc_read_counters(self._h, C.byref(c)))
+        return {"primary_rays": c.primary_rays, "hit_pixels": c.hit_pixels,
+                "shadow_rays": c.shadow_rays}
+
+
+def render_multi(scene, camera, W, H, n_devices, *, want_u8=False, shadows=True,
+                 face_mode=ESC_FACE_FIXED, fixed_face=0, seed=0, stage=ESC_STAGE_AUTO):
+    """Single-process row-band split over n_devices (bands share devices when there are
+    fewer GPUs than bands)."""
+    lib = _capi.load()
+    img = np.zeros((H, W, 3), np.float32)
+    u8 = np.zeros((H, W, 3), np.uint8) if want_u8 else None
+    ms = np.zeros(n_devices, np.float32)
+    o = _options(shadows, face_mode, fixed_face, seed, stage)
+    check(lib.esc_render_frame_multi(scene._h, C.byref(camera.c), W, H, C.byref(o), n_devices,
+                                     _fp(img),
+                                     u8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_u8 else None,
+                                     _fp(ms)))
+    return img, u8, ms
+
+
+def trace(W, H, lookfrom, lookat, vup, vfov, aspect, flat, debug=0, test=0):
+    """The ISPC drop-in symbol itself (trace.ispc:86-92 / main.cpp:619-624)."""
+    lib = _capi.load()
+    cam = _capi.ispc_cam()
+    lib.esc_new_ispc_cam(C.byref(cam), _fp(_f32(lookfrom, (3,))), _fp(_f32(lookat, (3,))),
+                         _fp(_f32(vup, (3,))), float(vfov), float(aspect))
+    img = np.zeros((H, W, 3), np.float32)
+    lib.trace(W, H, C.byref(cam), flat.num_triangles, flat.triangles, flat.num_lights,
+              flat.lights, flat.num_light_triangles, flat.light_triangles, _fp(img), debug, test)
+    return img
+
+
+def quantise(image):
+    img = _f32(image)
+    out = np.zeros(img.shape, np.uint8)
+    _capi.load().esc_quantise(_fp(img), img.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def write_ppm(path, image):
+    """main.cpp:658-689 P3 writer; image (H, W, 3) fp32 or uint8, h = 0 bottom row."""
+    lib = _capi.load()
+    H, W = image.shape[0], image.shape[1]
+    if image.dtype == np.uint8:
+        a = np.ascontiguousarray(image)
+        check(lib.esc_write_ppm_u8(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), W, H))
+    else:
+        a = _f32(image)
+        check(lib.esc_write_ppm(str(path).encode(), _fp(a), W, H))

@@ -1,0 +1,635 @@
+// rt_capi.cpp -- device half of the C ABI (include/esctp1_rt.h): context, scene staging
+// into HBM, row-band rendering, the `trace` drop-in.  HIP runtime API only; the kernels live
+// in rt_kernels.hip.  There is deliberately no CPU rendering path in this library: without a
+// gfx950 device every render entry point fails with ESC_ERR_NO_DEVICE / ESC_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../host/scene.h"
+#include "rt_device.h"
+
+extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
+                                  esc::DevSphP *sph_p, hipStream_t stream);
+extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, hipStream_t stream);
+
+using esc::set_error;
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+      return ESC_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+struct esc_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // staged scene (HBM)
+  esc::DevTri *d_tri = nullptr;
+  esc::DevTriP *d_tri_p = nullptr;
+  esc::DevTriN *d_tri_n = nullptr;
+  esc::DevSph *d_sph = nullptr;
+  esc::DevSphP *d_sph_p = nullptr;
+  int32_t *d_sph_mat = nullptr;
+  esc::DevMat *d_mat = nullptr;
+  esc::DevLight *d_lights = nullptr;
+  float *d_light_points = nullptr;
+  unsigned long long *d_counters = nullptr;
+  int n_tri = 0, n_sph = 0, n_lights = 0, n_geom = 0;
+  bool have_scene = false;
+  bool prepared = false;
+  float prepared_origin[3] = {0, 0, 0};
+  // scratch framebuffers for esc_render_frame_host
+  float *d_img = nullptr;
+  uint8_t *d_u8 = nullptr;
+  size_t img_cap = 0, u8_cap = 0;
+};
+
+namespace {
+
+// host-side image of the HBM tables, filled by either staging front-end
+struct Staged {
+  std::vector<esc::DevTri> tri;
+  std::vector<esc::DevTriN> tri_n; // empty when no geometry has normals
+  std::vector<esc::DevSph> sph;
+  std::vector<int32_t> sph_mat;
+  std::vector<esc::DevMat> mat;
+  std::vector<esc::DevLight> lights;
+  std::vector<float> light_points; // xyz0
+  int n_geom = 0;
+};
+
+esc::DevMat dev_material(const esc::Material &m, bool has_normals) {
+  esc::DevMat d;
+  std::memset(&d, 0, sizeof(d));
+  std::memcpy(d.ka, m.ka, 12);
+  std::memcpy(d.kd, m.kd, 12);
+  std::memcpy(d.ks, m.ks, 12);
+  std::memcpy(d.ke, m.ke, 12);
+  d.Ns = m.Ns;
+  d.has_normals = has_normals ? 1 : 0;
+  return d;
+}
+
+esc::DevTri dev_triangle(const float *v0, const float *v1, const float *v2, int geom) {
+  esc::DevTri t;
+  std::memset(&t, 0, sizeof(t));
+  for (int i = 0; i < 3; i++) {
+    t.v0[i] = v0[i];
+    t.e1[i] = v1[i] - v0[i]; // ray_triangle.h:14
+    t.e2[i] = v2[i] - v0[i]; // ray_triangle.h:15
+  }
+  t.geom = geom;
+  return t;
+}
+
+void push_light_point(Staged &s, const float *v) {
+  // main.cpp:753-754 with v0 = v1 = v2: P = v0 + ((v1-v0)*r1 + (v2-v0)*r2) = v0 + (+0)
+  s.light_points.push_back(v[0] + 0.0f);
+  s.light_points.push_back(v[1] + 0.0f);
+  s.light_points.push_back(v[2] + 0.0f);
+  s.light_points.push_back(0.0f);
+}
+
+int stage_scene(const esc_scene &scene, Staged &s) {
+  bool any_normals = false;
+  for (const auto &g : scene.geometry) any_normals |= !g.normals.empty();
+  s.n_geom = (int)scene.geometry.size();
+  for (size_t gi = 0; gi < scene.geometry.size(); gi++) { // main.cpp:179-180 order
+    const esc::Geometry &g = scene.geometry[gi];
+    const bool hn = !g.normals.empty();
+    s.mat.push_back(dev_material(g.object_material, hn));
+    for (size_t f = 0; f < g.n_faces(); f++) {
+      const uint32_t *face = &g.face_index[3 * f];
+      s.tri.push_back(dev_triangle(&g.vertex[3 * face[0]], &g.vertex[3 * face[1]],
+                                   &g.vertex[3 * face[2]], (int)gi));
+      if (any_normals) {
+        esc::DevTriN n;
+        std::memset(&n, 0, sizeof(n));
+        if (hn) {
+          std::memcpy(n.n0, &g.normals[3 * face[0]], 12);
+          std::memcpy(n.n1, &g.normals[3 * face[1]], 12);
+          std::memcpy(n.n2, &g.normals[3 * face[2]], 12);
+        }
+        s.tri_n.push_back(n);
+      }
+    }
+  }
+  for (size_t k = 0; k < scene.spheres.size(); k++) {
+    const esc::Sphere &sp = scene.spheres[k];
+    esc::DevSph d;
+    d.cx = sp.cx;
+    d.cy = sp.cy;
+    d.cz = sp.cz;
+    d.r2 = sp.r * sp.r;
+    s.sph.push_back(d);
+    s.sph_mat.push_back(s.n_geom + (int)k);
+    s.mat.push_back(dev_material(scene.sphere_materials[k], false));
+  }
+  for (size_t li : scene.light_sources) { // main.cpp:740-748
+    const esc::Geometry &g = scene.geometry[li];
+    if (g.n_faces() > g.n_vertices()) {
+      set_error("light geometry has more faces than vertices: light.vertex[faceID] "
+                "(main.cpp:748) would read out of range");
+      return ESC_ERR_INVALID;
+    }
+    esc::DevLight L;
+    L.first_point = (int)(s.light_points.size() / 4);
+    L.n_faces = (int)g.n_faces();
+    for (size_t k = 0; k < g.n_faces(); k++) push_light_point(s, &g.vertex[3 * k]);
+    s.lights.push_back(L);
+  }
+  return ESC_OK;
+}
+
+int stage_flat(int32_t nt, const ispc_triangle *tris, int32_t nl, const ispc_light *lights,
+               int32_t nlt, const ispc_triangle *ltris, Staged &s) {
+  int max_geom = -1;
+  bool any_normals = false;
+  for (int i = 0; i < nt; i++) {
+    if (tris[i].geom_id < 0) {
+      set_error("ispc_triangle.geom_id < 0");
+      return ESC_ERR_INVALID;
+    }
+    max_geom = std::max(max_geom, (int)tris[i].geom_id);
+    any_normals |= tris[i].has_normals != 0;
+  }
+  s.n_geom = max_geom + 1;
+  s.mat.resize((size_t)s.n_geom);
+  std::memset(s.mat.data(), 0, s.mat.size() * sizeof(esc::DevMat));
+  for (int i = 0; i < nt; i++) {
+    const ispc_triangle &t = tris[i];
+    s.tri.push_back(dev_triangle(t.vertices[0], t.vertices[1], t.vertices[2], t.geom_id));
+    esc::DevMat &m = s.mat[(size_t)t.geom_id]; // material is replicated per triangle
+    std::memcpy(m.ka, t.ka, 12);
+    std::memcpy(m.kd, t.kd, 12);
+    std::memcpy(m.ks, t.ks, 12);
+    std::memcpy(m.ke, t.ke, 12);
+    m.Ns = t.Ns;
+    m.has_normals = t.has_normals ? 1 : 0;
+    if (any_normals) {
+      esc::DevTriN n;
+      std::memset(&n, 0, sizeof(n));
+      if (t.has_normals) {
+        std::memcpy(n.n0, t.normals[0], 12);
+        std::memcpy(n.n1, t.normals[1], 12);
+        std::memcpy(n.n2, t.normals[2], 12);
+      }
+      s.tri_n.push_back(n);
+    }
+  }
+  for (int li = 0; li < nl; li++) {
+    const ispc_light &L = lights[li];
+    esc::DevLight D;
+    D.first_point = (int)(s.light_points.size() / 4);
+    D.n_faces = L.num_light_faces;
+    // the scalar path's light.vertex[k], k < n_faces, is corner k%3 of light face k/3
+    for (int k = 0; k < L.num_light_faces; k++) {
+      const int fi = L.light_faces[k / 3];
+      if (fi < 0 || fi >= nlt) {
+        set_error("ispc_light.light_faces index out of range");
+        return ESC_ERR_INVALID;
+      }
+      push_light_point(s, ltris[fi].vertices[k % 3]);
+    }
+    s.lights.push_back(D);
+  }
+  return ESC_OK;
+}
+
+template <typename T> int upload_vec(T *&dptr, const std::vector<T> &h, hipStream_t st) {
+  if (dptr) {
+    HIP_TRY(hipFree(dptr));
+    dptr = nullptr;
+  }
+  if (h.empty()) return ESC_OK;
+  HIP_TRY(hipMalloc((void **)&dptr, h.size() * sizeof(T)));
+  HIP_TRY(hipMemcpyAsync(dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  return ESC_OK;
+}
+
+template <typename T> int alloc_dev(T *&dptr, size_t n) {
+  if (dptr) {
+    HIP_TRY(hipFree(dptr));
+    dptr = nullptr;
+  }
+  if (n == 0) return ESC_OK;
+  HIP_TRY(hipMalloc((void **)&dptr, n * sizeof(T)));
+  return ESC_OK;
+}
+
+int commit(esc_context *ctx, const Staged &s) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read old tables
+  int rc;
+  if ((rc = upload_vec(ctx->d_tri, s.tri, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_tri_n, s.tri_n, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_sph, s.sph, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_sph_mat, s.sph_mat, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_mat, s.mat, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_lights, s.lights, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_light_points, s.light_points, ctx->stream))) return rc;
+  if ((rc = alloc_dev(ctx->d_tri_p, s.tri.size()))) return rc;
+  if ((rc = alloc_dev(ctx->d_sph_p, s.sph.size()))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream)); // host vectors die with the caller's frame
+  ctx->n_tri = (int)s.tri.size();
+  ctx->n_sph = (int)s.sph.size();
+  ctx->n_lights = (int)s.lights.size();
+  ctx->n_geom = s.n_geom;
+  ctx->have_scene = true;
+  ctx->prepared = false;
+  return ESC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int esc_context_create(int32_t device, esc_context **out) {
+  if (!out) {
+    set_error("esc_context_create: out is null");
+    return ESC_ERR_INVALID;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error(std::string("no HIP device available (") +
+              (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+              "); this renderer has no CPU fallback");
+    return ESC_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("esc_context_create: device index out of range");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(device));
+  esc_context *ctx = new (std::nothrow) esc_context();
+  if (!ctx) return ESC_ERR_NOMEM;
+  ctx->device = device;
+  hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) {
+    set_error(std::string("hipStreamCreate: ") + hipGetErrorString(se));
+    delete ctx;
+    return ESC_ERR_HIP;
+  }
+  ctx->own_stream = true;
+  hipError_t ce = hipMalloc((void **)&ctx->d_counters, 3 * sizeof(unsigned long long));
+  if (ce == hipSuccess) ce = hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long));
+  if (ce != hipSuccess) {
+    set_error(std::string("hipMalloc(counters): ") + hipGetErrorString(ce));
+    esc_context_destroy(ctx);
+    return ESC_ERR_HIP;
+  }
+  *out = ctx;
+  return ESC_OK;
+}
+
+void esc_context_destroy(esc_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
+                  ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
+                  ctx->d_counters, ctx->d_img,  ctx->d_u8};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int esc_context_set_stream(esc_context *ctx, void *hip_stream) {
+  if (!ctx) {
+    set_error("esc_context_set_stream: ctx is null");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  return ESC_OK;
+}
+
+void *esc_context_stream(esc_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int esc_context_synchronize(esc_context *ctx) {
+  if (!ctx) {
+    set_error("esc_context_synchronize: ctx is null");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ESC_OK;
+}
+
+int esc_upload_scene(esc_context *ctx, const esc_scene *scene) {
+  if (!ctx || !scene) {
+    set_error("esc_upload_scene: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  Staged s;
+  int rc = stage_scene(*scene, s);
+  if (rc) return rc;
+  return commit(ctx, s);
+}
+
+int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle *triangles,
+                    int32_t num_lights, const ispc_light *lights, int32_t num_light_triangles,
+                    const ispc_triangle *light_triangles) {
+  if (!ctx || num_triangles < 0 || num_lights < 0 || num_light_triangles < 0 ||
+      (num_triangles && !triangles) || (num_lights && !lights) ||
+      (num_light_triangles && !light_triangles)) {
+    set_error("esc_upload_flat: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  Staged s;
+  int rc = stage_flat(num_triangles, triangles, num_lights, lights, num_light_triangles,
+                      light_triangles, s);
+  if (rc) return rc;
+  return commit(ctx, s);
+}
+
+int esc_render_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
+                    int32_t row_begin, int32_t row_end, const esc_render_options *opts,
+                    float *d_rgb_f32, uint8_t *d_rgb_u8) {
+  if (!ctx || !cam || !opts) {
+    set_error("esc_render_rows: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (!ctx->have_scene) {
+    set_error("esc_render_rows: no scene uploaded");
+    return ESC_ERR_INVALID;
+  }
+  if (W < 2 || H < 2 || row_begin < 0 || row_end > H || row_begin > row_end) {
+    // W-1 and H-1 are divisors at main.cpp:709-710
+    set_error("esc_render_rows: need W,H >= 2 and 0 <= row_begin <= row_end <= H");
+    return ESC_ERR_INVALID;
+  }
+  if ((int64_t)W * H > 0x7fffffffLL) {
+    set_error("esc_render_rows: W*H exceeds the reference's int pixel index (main.cpp:784)");
+    return ESC_ERR_INVALID;
+  }
+  if (opts->face_mode == ESC_FACE_FIXED && opts->fixed_face < 0) {
+    set_error("esc_render_rows: fixed_face < 0");
+    return ESC_ERR_INVALID;
+  }
+  if (row_begin == row_end) return ESC_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+
+  esc::RenderParams p;
+  std::memset(&p, 0, sizeof(p));
+  std::memcpy(p.origin, cam->origin, 12);
+  std::memcpy(p.llc, cam->lower_left_corner, 12);
+  std::memcpy(p.horizontal, cam->horizontal, 12);
+  std::memcpy(p.vertical, cam->vertical, 12);
+  p.W = W;
+  p.H = H;
+  p.row_begin = row_begin;
+  p.row_end = row_end;
+  p.n_tri = ctx->n_tri;
+  p.n_sph = ctx->n_sph;
+  p.n_lights = ctx->n_lights;
+  p.n_geom = ctx->n_geom;
+  p.tri = ctx->d_tri;
+  p.tri_p = ctx->d_tri_p;
+  p.tri_n = ctx->d_tri_n;
+  p.sph = ctx->d_sph;
+  p.sph_p = ctx->d_sph_p;
+  p.sph_mat = ctx->d_sph_mat;
+  p.mat = ctx->d_mat;
+  p.lights = ctx->d_lights;
+  p.light_points = ctx->d_light_points;
+  p.shadows = opts->shadows ? 1 : 0;
+  p.face_mode = opts->face_mode;
+  p.fixed_face = opts->fixed_face;
+  p.seed = opts->seed;
+  p.out_f32 = d_rgb_f32;
+  p.out_u8 = d_rgb_u8;
+  p.counters = ctx->d_counters;
+
+  if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
+    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_sph_p, ctx->stream);
+    if (e) {
+      set_error(std::string("k_prepare_primary launch: ") + hipGetErrorString((hipError_t)e));
+      return ESC_ERR_HIP;
+    }
+    std::memcpy(ctx->prepared_origin, cam->origin, 12);
+    ctx->prepared = true;
+  }
+  const int stage = (opts->stage == ESC_STAGE_LDS) ? 2 : 1; // AUTO -> SMEM (measured)
+  int e = esc_launch_render(&p, stage, ctx->stream);
+  if (e) {
+    set_error(std::string("k_render launch: ") + hipGetErrorString((hipError_t)e));
+    return ESC_ERR_HIP;
+  }
+  return ESC_OK;
+}
+
+int esc_reset_counters(esc_context *ctx) {
+  if (!ctx) {
+    set_error("esc_reset_counters: ctx is null");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
+  return ESC_OK;
+}
+
+int esc_read_counters(esc_context *ctx, esc_counters *out) {
+  if (!ctx || !out) {
+    set_error("esc_read_counters: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  unsigned long long h[3];
+  HIP_TRY(hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  out->primary_rays = h[0];
+  out->hit_pixels = h[1];
+  out->shadow_rays = h[2];
+  return ESC_OK;
+}
+
+int esc_render_frame_host(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
+                          const esc_render_options *opts, float *image, uint8_t *rgb8) {
+  if (!ctx || (!image && !rgb8)) {
+    set_error("esc_render_frame_host: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (W < 2 || H < 2) {
+    set_error("esc_render_frame_host: need W,H >= 2");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = (size_t)W * H * 3;
+  if (image && ctx->img_cap < n) {
+    if (ctx->d_img) HIP_TRY(hipFree(ctx->d_img));
+    ctx->d_img = nullptr;
+    ctx->img_cap = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->d_img, n * sizeof(float)));
+    ctx->img_cap = n;
+  }
+  if (rgb8 && ctx->u8_cap < n) {
+    if (ctx->d_u8) HIP_TRY(hipFree(ctx->d_u8));
+    ctx->d_u8 = nullptr;
+    ctx->u8_cap = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->d_u8, n));
+    ctx->u8_cap = n;
+  }
+  int rc = esc_render_rows(ctx, cam, W, H, 0, H, opts, image ? ctx->d_img : nullptr,
+                           rgb8 ? ctx->d_u8 : nullptr);
+  if (rc) return rc;
+  if (image)
+    HIP_TRY(hipMemcpyAsync(image, ctx->d_img, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, ctx->d_u8, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ESC_OK;
+}
+
+int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_t W, int32_t H,
+                           const esc_render_options *opts, int32_t n_devices, float *image,
+                           uint8_t *rgb8, float *ms_per_device) {
+  if (!scene || !cam || !opts || n_devices < 1 || (!image && !rgb8)) {
+    set_error("esc_render_frame_multi: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (W < 2 || H < 2 || n_devices > H) {
+    set_error("esc_render_frame_multi: need W,H >= 2 and n_devices <= H");
+    return ESC_ERR_INVALID;
+  }
+  int avail = 0;
+  if (hipGetDeviceCount(&avail) != hipSuccess || avail < 1) {
+    set_error("esc_render_frame_multi: no HIP device (no CPU fallback)");
+    return ESC_ERR_NO_DEVICE;
+  }
+  struct Band {
+    esc_context *ctx = nullptr;
+    float *d_img = nullptr;
+    uint8_t *d_u8 = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int r0 = 0, r1 = 0;
+  };
+  std::vector<Band> bands((size_t)n_devices);
+  int rc = ESC_OK;
+  auto cleanup = [&]() {
+    for (auto &b : bands) {
+      if (!b.ctx) continue;
+      (void)hipSetDevice(b.ctx->device);
+      if (b.d_img) (void)hipFree(b.d_img);
+      if (b.d_u8) (void)hipFree(b.d_u8);
+      if (b.t0) (void)hipEventDestroy(b.t0);
+      if (b.t1) (void)hipEventDestroy(b.t1);
+      esc_context_destroy(b.ctx);
+    }
+  };
+#define MULTI_TRY(expr)                                                      \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+      cleanup();                                                             \
+      return ESC_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)
+  const int rows_per = H / n_devices;
+  // phase 1: one context per band; bands beyond the device count share devices round-robin
+  for (int i = 0; i < n_devices && rc == ESC_OK; i++) {
+    Band &b = bands[(size_t)i];
+    b.r0 = i * rows_per;
+    b.r1 = (i == n_devices - 1) ? H : (i + 1) * rows_per;
+    rc = esc_context_create(i % avail, &b.ctx);
+    if (rc == ESC_OK) rc = esc_upload_scene(b.ctx, scene);
+  }
+  if (rc != ESC_OK) {
+    cleanup();
+    return rc;
+  }
+  // phase 2: launch every band before waiting on any
+  for (auto &b : bands) {
+    const size_t n = (size_t)(b.r1 - b.r0) * W * 3;
+    MULTI_TRY(hipSetDevice(b.ctx->device));
+    if (image) MULTI_TRY(hipMalloc((void **)&b.d_img, n * sizeof(float)));
+    if (rgb8) MULTI_TRY(hipMalloc((void **)&b.d_u8, n));
+    MULTI_TRY(hipEventCreate(&b.t0));
+    MULTI_TRY(hipEventCreate(&b.t1));
+    MULTI_TRY(hipEventRecord(b.t0, b.ctx->stream));
+    rc = esc_render_rows(b.ctx, cam, W, H, b.r0, b.r1, opts, b.d_img, b.d_u8);
+    if (rc != ESC_OK) {
+      cleanup();
+      return rc;
+    }
+    MULTI_TRY(hipEventRecord(b.t1, b.ctx->stream));
+    // gather: each band lands at its row offset of the caller's frame
+    if (image)
+      MULTI_TRY(hipMemcpyAsync(image + (size_t)b.r0 * W * 3, b.d_img, n * sizeof(float),
+                               hipMemcpyDeviceToHost, b.ctx->stream));
+    if (rgb8)
+      MULTI_TRY(hipMemcpyAsync(rgb8 + (size_t)b.r0 * W * 3, b.d_u8, n, hipMemcpyDeviceToHost,
+                               b.ctx->stream));
+  }
+  for (size_t i = 0; i < bands.size(); i++) {
+    Band &b = bands[i];
+    MULTI_TRY(hipSetDevice(b.ctx->device));
+    MULTI_TRY(hipStreamSynchronize(b.ctx->stream));
+    if (ms_per_device) MULTI_TRY(hipEventElapsedTime(&ms_per_device[i], b.t0, b.t1));
+  }
+#undef MULTI_TRY
+  cleanup();
+  return ESC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// the ISPC drop-in (trace.ispc:86-92 / main.cpp:619-624)
+// ---------------------------------------------------------------------------------------
+void trace(int32_t image_width, int32_t image_height, ispc_cam *cam, int32_t num_triangles,
+           ispc_triangle triangles[], int32_t num_lights, ispc_light lights[],
+           int32_t num_light_triangles, ispc_triangle light_triangles[], float *return_image,
+           int32_t debug, int32_t test) {
+  (void)test; // accepted and ignored, like trace.ispc:92 (defect I6)
+  if (!return_image || image_width <= 0 || image_height <= 0) return;
+  const size_t n = (size_t)image_width * image_height * 3;
+  std::memset(return_image, 0, n * sizeof(float)); // overwrite semantics (defect I3)
+  static esc_context *ctx = nullptr; // one per process, like the single call site
+  int rc = ESC_OK;
+  if (!ctx) {
+    const char *dev = std::getenv("ESC_DEVICE");
+    rc = esc_context_create(dev ? std::atoi(dev) : 0, &ctx);
+  }
+  if (rc == ESC_OK)
+    rc = esc_upload_flat(ctx, num_triangles, triangles, num_lights, lights, num_light_triangles,
+                         light_triangles);
+  if (rc == ESC_OK) {
+    if (!cam) {
+      set_error("trace: cam is null");
+      rc = ESC_ERR_INVALID;
+    }
+  }
+  if (rc == ESC_OK) {
+    esc_camera c;
+    esc_camera_init(&c, cam->lookfrom, cam->lookat, cam->vup, cam->vfov, cam->aspect);
+    esc_render_options o;
+    std::memset(&o, 0, sizeof(o));
+    o.shadows = 1;
+    o.face_mode = ESC_FACE_HASH; // == face 0 for single-face lights
+    o.seed = 0;
+    rc = esc_render_frame_host(ctx, &c, image_width, image_height, &o, return_image, nullptr);
+  }
+  if (rc != ESC_OK) {
+    std::fprintf(stderr, "esctp1raytracer_amd trace(): error %d: %s\n", rc, esc_last_error());
+    std::memset(return_image, 0, n * sizeof(float));
+  } else if (debug >= 2) {
+    std::fprintf(stderr, "esctp1raytracer_amd trace(): w=%d h=%d triangles=%d lights=%d\n",
+                 image_width, image_height, num_triangles, num_lights);
+  }
+}
+
+} // extern "C"

@@ -1,0 +1,101 @@
+// rt_device.h -- HBM layout of the staged scene and the kernel parameter block.
+// Shared by rt_kernels.hip (device) and rt_capi.cpp (host staging).
+//
+// The reference walks AoS geometry -> face_index -> vertex for every ray
+// (main.cpp:179-186).  Here every primitive is one fixed-size record in a flat table that
+// a whole wavefront reads at the same address at the same time (wave-uniform), so it can
+// come from the scalar cache into SGPRs or from an LDS broadcast.  Everything stored is
+// either an input value or the result of the SAME fp32 operation the reference performs
+// per ray (edge1 = v1 - v0 etc., ray_triangle.h:14-15), so precomputing it cannot change
+// a bit of the result.
+#pragma once
+#include <stdint.h>
+
+namespace esc {
+
+// ray_triangle.h:14-15 operands, 48 B.  Used by shadow rays (origin differs per pixel)
+// and by shading (main.cpp:728-731 uses the same two edge vectors).
+struct alignas(16) DevTri {
+  float v0[3];
+  float e1[3]; // vert1 - vert0
+  float e2[3]; // vert2 - vert0
+  int32_t geom; // material / geometry id
+  int32_t pad[2];
+};
+
+// Primary rays share one origin (camera.h:32), so tvec, qvec and dot(edge2,qvec)
+// (ray_triangle.h:29,37,45) are per-triangle constants for the frame.  64 B.
+struct alignas(16) DevTriP {
+  float e2[3];
+  float e1[3];
+  float tv[3]; // orig - vert0
+  float qv[3]; // cross(tvec, edge1)
+  float tnum;  // dot(edge2, qvec)
+  float pad[3];
+};
+
+// sphere extension: general form, r2 = r*r
+struct alignas(16) DevSph {
+  float cx, cy, cz, r2;
+};
+// primary form: oc = orig - c, cc = dot(oc,oc) - r2
+struct alignas(16) DevSphP {
+  float ocx, ocy, ocz, cc;
+};
+
+// scene.h:11-18 Material + whether the owning geometry has normals (main.cpp:733)
+struct alignas(16) DevMat {
+  float ka[3];
+  float kd[3];
+  float ks[3];
+  float ke[3];
+  float Ns;
+  int32_t has_normals;
+  int32_t pad[2];
+};
+
+// per-triangle vertex normals, only read at shading (main.cpp:734-737)
+struct DevTriN {
+  float n0[3];
+  float n1[3];
+  float n2[3];
+};
+
+// quirk S2 (main.cpp:748-754): the light sample is light.vertex[faceID] itself; the
+// candidate points (first n_faces vertices of the light geometry, each "+ 0.0f") are
+// stored back to back in light_points.
+struct DevLight {
+  int32_t first_point;
+  int32_t n_faces;
+};
+
+struct RenderParams {
+  // camera.h:36-39
+  float origin[3];
+  float llc[3];
+  float horizontal[3];
+  float vertical[3];
+  int32_t W, H, row_begin, row_end;
+  int32_t n_tri, n_sph, n_lights, n_geom;
+  const DevTri *tri;
+  const DevTriP *tri_p;
+  const DevTriN *tri_n; // nullptr when no geometry has normals
+  const DevSph *sph;
+  const DevSphP *sph_p;
+  const int32_t *sph_mat; // material index of sphere k (already offset by n_geom)
+  const DevMat *mat;      // [n_geom + n_sphere_materials]
+  const DevLight *lights;
+  const float *light_points; // xyz0 per candidate point
+  int32_t shadows, face_mode, fixed_face, pad0;
+  uint64_t seed;
+  float *out_f32;   // band-local, may be null
+  uint8_t *out_u8;  // band-local, may be null
+  unsigned long long *counters; // [3] primary, hit, shadow
+};
+
+// pixel tile of one 256-thread workgroup: 4 waves as 2x2 tiles of 16x4 pixels
+constexpr int kTileW = 32;
+constexpr int kTileH = 8;
+constexpr int kLdsChunkBytes = 32768; // LDS staging chunk (ESC_STAGE_LDS)
+
+} // namespace esc

@@ -1,0 +1,565 @@
+// rt_kernels.hip -- hand-written gfx950 kernels for the per-pixel render loop of
+// pg42819/EscTp1RayTracer (reference paths relative to /root/reference):
+//
+//   k_prepare_primary  per-frame, per-primitive constants for rays leaving the camera origin
+//   k_render<STAGE>    one work-item per pixel: camera.h:31-34 get_ray -> main.cpp:176-192
+//                      closest hit -> main.cpp:723-789 normal + per-light shadow ray
+//                      (main.cpp:314-329) + Phong -> fp32 RGB and/or PPM-quantised bytes
+//
+// Arithmetic contract: this file MUST be compiled with -ffp-contract=off (hipcc would
+// otherwise fuse a*b+c into v_fma_f32 and flip pixels) and with
+// correctly rounded fp32 divide/sqrt (hipcc default).  Every expression is evaluated in the
+// order the reference evaluates it.  The one liberty taken: vec.h:95-101 starts its dot
+// product from `sum = 0`; the leading `0 +` is dropped here.  That can only turn a -0 result
+// into +0, and every dot product on this path is either a sum of squares (never -0), or is
+// compared against a positive threshold / multiplied by other terms where +-0 behave alike
+// (det, u, v, t numerators; d = dot(N,L) tested with `<= 0`; b of the sphere test is squared
+// and its -b +- sqrt fallbacks land on the same side of FLT_EPSILON).
+//
+// Lanes are pixels, so the closest hit is lane-private; primitives are wave-uniform and
+// come either through the scalar cache into SGPRs (STAGE_SMEM) or through an LDS chunk the
+// workgroup stages (STAGE_LDS).  Inputs must be finite.
+#include <float.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+
+namespace esc {
+
+#define DEVINL __device__ __forceinline__
+
+constexpr int STAGE_SMEM = 1;
+constexpr int STAGE_LDS = 2;
+
+struct f3 {
+  float x, y, z;
+};
+DEVINL f3 mk(float x, float y, float z) {
+  f3 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  return r;
+}
+DEVINL f3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+DEVINL f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); } // vec.h:111
+DEVINL f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); } // vec.h:115
+DEVINL f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }    // vec.h:127
+DEVINL f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }    // vec.h:119
+DEVINL float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }   // vec.h:95
+DEVINL f3 cross(f3 a, f3 b) {                                                   // vec.h:103
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+DEVINL f3 normalize(f3 v) { return v / sqrtf(dot(v, v)); } // vec.h:135
+DEVINL float length(f3 v) { return sqrtf(dot(v, v)); }     // vec.h:139
+
+// ---------------------------------------------------------------------------------------
+// exact tails (rare paths)
+// ---------------------------------------------------------------------------------------
+
+// ray_triangle.h:21-54 given the fp32 numerators.  Returns true on accept.
+DEVINL bool tri_exact(float detf, float unum, float vnum, float tnum, float tbound, float &t2o,
+                      float &v2o) {
+  const double eps = (double)FLT_EPSILON;
+  double det = (double)detf;                    // :21
+  if (det > -eps && det < eps) return false;    // :23-25
+  double inv_det = 1.0 / det;                   // :26 (1.0f widened)
+  float u2 = (float)((double)unum * inv_det);   // :32
+  if (u2 < FLT_EPSILON || u2 > 1.0f) return false; // :33
+  float v2 = (float)((double)vnum * inv_det);   // :40
+  if (v2 < FLT_EPSILON || u2 + v2 > 1.0f) return false; // :41
+  float t2 = (float)((double)tnum * inv_det);   // :45
+  if (t2 < FLT_EPSILON) return false;           // :46
+  if (t2 >= tbound) return false;               // :49
+  t2o = t2;
+  v2o = v2;
+  return true;
+}
+
+// Conservative fp32 pre-reject for the u/v barycentric tests: true means "cannot be
+// rejected cheaply, run tri_exact".  With s = sign(det): u2 < eps whenever unum*s <= 0,
+// v2 < eps whenever vnum*s <= 0, and u2 + v2 > 1 whenever |unum + vnum| > |det|*(1+1e-5)
+// (the fp32 / f64 roundings involved are < 2e-7 relative).  Never rejects an accept.
+DEVINL bool tri_candidate(float detf, float unum, float vnum) {
+  const uint32_t db = __float_as_uint(detf);
+  const uint32_t sg = ((__float_as_uint(unum) ^ db) | (__float_as_uint(vnum) ^ db));
+  const float sum = unum + vnum;
+  const float m = fabsf(detf) * 1.00001f;
+  return ((int32_t)sg >= 0) && !(fabsf(sum) > m);
+}
+
+// sphere extension from b and disc; accept iff all three rejects fail.
+DEVINL bool sph_exact(float b, float disc, float tbound, float &t2o) {
+  if (disc < 0.f) return false;
+  float sq = sqrtf(disc);
+  float t2 = -b - sq;
+  if (t2 < FLT_EPSILON) t2 = -b + sq;
+  if (t2 < FLT_EPSILON) return false;
+  if (t2 >= tbound) return false;
+  t2o = t2;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-frame constants for primary rays
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, int n_tri,
+                  const DevSph *__restrict__ sph, DevSphP *__restrict__ sph_p, int n_sph,
+                  float ox, float oy, float oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const f3 o = mk(ox, oy, oz);
+  if (i < n_tri) {
+    const DevTri T = tri[i];
+    const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+    const f3 tv = o - ld3(T.v0);   // ray_triangle.h:29
+    const f3 qv = cross(tv, e1);   // :37
+    DevTriP P;
+    P.e2[0] = e2.x; P.e2[1] = e2.y; P.e2[2] = e2.z;
+    P.e1[0] = e1.x; P.e1[1] = e1.y; P.e1[2] = e1.z;
+    P.tv[0] = tv.x; P.tv[1] = tv.y; P.tv[2] = tv.z;
+    P.qv[0] = qv.x; P.qv[1] = qv.y; P.qv[2] = qv.z;
+    P.tnum = dot(e2, qv);          // :45 numerator
+    P.pad[0] = P.pad[1] = P.pad[2] = 0.f;
+    tri_p[i] = P;
+  }
+  if (i < n_sph) {
+    const DevSph S = sph[i];
+    const f3 oc = o - mk(S.cx, S.cy, S.cz);
+    DevSphP P;
+    P.ocx = oc.x;
+    P.ocy = oc.y;
+    P.ocz = oc.z;
+    P.cc = dot(oc, oc) - S.r2;
+    sph_p[i] = P;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// primitive loops.  `rec(k)` yields record k wave-uniformly (SGPRs or LDS broadcast).
+// ---------------------------------------------------------------------------------------
+
+struct Hit {
+  float t;     // main.cpp:715 FLT_MAX, then closest t
+  float v;     // quirk S1: only v survives (main.cpp:307,310)
+  int32_t idx; // -1 none; [0,n_tri) triangle; n_tri + k sphere k
+};
+
+// closest hit, primary rays, triangles [k0, k0+n)
+template <typename Fetch>
+DEVINL void closest_tri_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
+  int k = 0;
+  for (; k + 2 <= n; k += 2) {
+    const DevTriP A = rec(k), B = rec(k + 1);
+    const f3 pa = cross(d, ld3(A.e2)), pb = cross(d, ld3(B.e2)); // ray_triangle.h:18
+    const float da = dot(ld3(A.e1), pa), db = dot(ld3(B.e1), pb); // :21
+    const float ua = dot(ld3(A.tv), pa), ub = dot(ld3(B.tv), pb); // :32 numerator
+    const float va = dot(d, ld3(A.qv)), vb = dot(d, ld3(B.qv));   // :40 numerator
+    const bool ca = tri_candidate(da, ua, va), cb = tri_candidate(db, ub, vb);
+    if (__builtin_amdgcn_ballot_w64(ca | cb)) { // wave-uniform skip of the f64 tail
+      float t2, v2;
+      if (ca && tri_exact(da, ua, va, A.tnum, h.t, t2, v2)) {
+        h.t = t2;
+        h.v = v2;
+        h.idx = base + k;
+      }
+      if (cb && tri_exact(db, ub, vb, B.tnum, h.t, t2, v2)) {
+        h.t = t2;
+        h.v = v2;
+        h.idx = base + k + 1;
+      }
+    }
+  }
+  for (; k < n; ++k) {
+    const DevTriP A = rec(k);
+    const f3 pa = cross(d, ld3(A.e2));
+    const float da = dot(ld3(A.e1), pa);
+    const float ua = dot(ld3(A.tv), pa);
+    const float va = dot(d, ld3(A.qv));
+    float t2, v2;
+    if (tri_candidate(da, ua, va) && tri_exact(da, ua, va, A.tnum, h.t, t2, v2)) {
+      h.t = t2;
+      h.v = v2;
+      h.idx = base + k;
+    }
+  }
+}
+
+// closest hit, primary rays, spheres
+template <typename Fetch>
+DEVINL void closest_sph_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
+  int k = 0;
+  for (; k + 4 <= n; k += 4) {
+    const DevSphP s0 = rec(k), s1 = rec(k + 1), s2 = rec(k + 2), s3 = rec(k + 3);
+    const float b0 = (s0.ocx * d.x + s0.ocy * d.y) + s0.ocz * d.z;
+    const float b1 = (s1.ocx * d.x + s1.ocy * d.y) + s1.ocz * d.z;
+    const float b2 = (s2.ocx * d.x + s2.ocy * d.y) + s2.ocz * d.z;
+    const float b3 = (s3.ocx * d.x + s3.ocy * d.y) + s3.ocz * d.z;
+    const float q0 = b0 * b0 - s0.cc, q1 = b1 * b1 - s1.cc;
+    const float q2 = b2 * b2 - s2.cc, q3 = b3 * b3 - s3.cc;
+    const float m = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+    if (__builtin_amdgcn_ballot_w64(!(m < 0.f))) {
+      float t2;
+      if (sph_exact(b0, q0, h.t, t2)) { h.t = t2; h.idx = base + k; }
+      if (sph_exact(b1, q1, h.t, t2)) { h.t = t2; h.idx = base + k + 1; }
+      if (sph_exact(b2, q2, h.t, t2)) { h.t = t2; h.idx = base + k + 2; }
+      if (sph_exact(b3, q3, h.t, t2)) { h.t = t2; h.idx = base + k + 3; }
+    }
+  }
+  for (; k < n; ++k) {
+    const DevSphP s0 = rec(k);
+    const float b0 = (s0.ocx * d.x + s0.ocy * d.y) + s0.ocz * d.z;
+    const float q0 = b0 * b0 - s0.cc;
+    float t2;
+    if (sph_exact(b0, q0, h.t, t2)) { h.t = t2; h.idx = base + k; }
+  }
+}
+
+// any-hit (main.cpp:314-329), general origin.  tb = per-lane bound: > 0 while the lane is
+// still looking, set to 0 once it found its FIRST occluder (or if it never looked), so later
+// primitives cannot accept (accepts need eps <= t2 < tb).  tocc receives that occluder's t2
+// (occlusion() mutates the caller's t, quirk S3).
+template <typename Fetch>
+DEVINL void anyhit_tri(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
+  for (int k = 0; k < n; ++k) {
+    if ((k & 3) == 0 && !__builtin_amdgcn_ballot_w64(tb > 0.f)) return; // every lane done
+    const DevTri T = rec(k);
+    const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+    const f3 pv = cross(L, e2);          // ray_triangle.h:18
+    const float det = dot(e1, pv);       // :21
+    const f3 tv = o - ld3(T.v0);         // :29
+    const float un = dot(tv, pv);        // :32
+    const f3 qv = cross(tv, e1);         // :37
+    const float vn = dot(L, qv);         // :40
+    const bool c = tri_candidate(det, un, vn);
+    if (__builtin_amdgcn_ballot_w64(c)) {
+      float t2, v2;
+      if (c && tri_exact(det, un, vn, dot(e2, qv), tb, t2, v2)) {
+        tocc = t2;
+        tb = 0.f;
+      }
+    }
+  }
+}
+
+template <typename Fetch>
+DEVINL void anyhit_sph(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
+  int k = 0;
+  for (; k + 2 <= n; k += 2) {
+    if ((k & 7) == 0 && !__builtin_amdgcn_ballot_w64(tb > 0.f)) return;
+    const DevSph s0 = rec(k), s1 = rec(k + 1);
+    const f3 oc0 = mk(o.x - s0.cx, o.y - s0.cy, o.z - s0.cz);
+    const f3 oc1 = mk(o.x - s1.cx, o.y - s1.cy, o.z - s1.cz);
+    const float b0 = dot(oc0, L), b1 = dot(oc1, L);
+    const float c0 = dot(oc0, oc0) - s0.r2, c1 = dot(oc1, oc1) - s1.r2;
+    const float q0 = b0 * b0 - c0, q1 = b1 * b1 - c1;
+    if (__builtin_amdgcn_ballot_w64(!(fmaxf(q0, q1) < 0.f))) {
+      float t2;
+      if (sph_exact(b0, q0, tb, t2)) { tocc = t2; tb = 0.f; }
+      if (sph_exact(b1, q1, tb, t2)) { tocc = t2; tb = 0.f; }
+    }
+  }
+  for (; k < n; ++k) {
+    const DevSph s0 = rec(k);
+    const f3 oc0 = mk(o.x - s0.cx, o.y - s0.cy, o.z - s0.cz);
+    const float b0 = dot(oc0, L);
+    const float q0 = b0 * b0 - (dot(oc0, oc0) - s0.r2);
+    float t2;
+    if (sph_exact(b0, q0, tb, t2)) { tocc = t2; tb = 0.f; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// staging front-ends
+// ---------------------------------------------------------------------------------------
+
+// SMEM: the table pointer and index are wave-uniform, so hipcc emits s_load_dwordx4/x8/x16
+// and the VALU takes the values straight from SGPRs.
+template <typename Rec> struct SmemFetch {
+  const Rec *__restrict__ p;
+  DEVINL Rec operator()(int k) const { return p[k]; }
+};
+
+// LDS: the workgroup copies a chunk of the table into LDS (16 B per lane per step,
+// coalesced), then every lane reads record k at the same address (broadcast ds_read_b128).
+template <typename Rec> struct LdsFetch {
+  const Rec *p;
+  DEVINL Rec operator()(int k) const { return p[k]; }
+};
+
+template <typename Rec>
+DEVINL void lds_stage(Rec *lds, const Rec *__restrict__ src, int n) {
+  const uint4 *s = reinterpret_cast<const uint4 *>(src);
+  uint4 *d = reinterpret_cast<uint4 *>(lds);
+  const int n16 = n * (int)(sizeof(Rec) / 16);
+  for (int i = threadIdx.x; i < n16; i += blockDim.x) d[i] = s[i];
+}
+
+// splitmix64 finaliser over (seed, pixel, light): counter-based stand-in for the
+// reference's mt19937 draw at main.cpp:743-747 (bit-identical to oracle/rt_oracle.c).
+DEVINL uint32_t face_hash(uint64_t seed, uint32_t pixel, uint32_t light, uint32_t n_faces) {
+  uint64_t z = seed + (((uint64_t)pixel << 32) | (uint64_t)light) + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)((z >> 32) % (uint64_t)n_faces);
+}
+
+// ---------------------------------------------------------------------------------------
+// the frame kernel
+// ---------------------------------------------------------------------------------------
+template <int STAGE>
+__global__ void __launch_bounds__(256) k_render(const RenderParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
+  __shared__ float lds_px[kTileW * kTileH * 3];
+
+  // ---- workgroup -> pixel tile.  Blocks are dealt round-robin over the 8 XCDs, so block b
+  // and b+8 share an L2; give each XCD one contiguous run of tiles (= contiguous framebuffer
+  // rows) instead of every 8th tile.  Grid is padded to a multiple of 8; surplus blocks exit.
+  const int rows = p.row_end - p.row_begin;
+  const int tiles_x = (p.W + kTileW - 1) / kTileW;
+  const int tiles_y = (rows + kTileH - 1) / kTileH;
+  const int n_tiles = tiles_x * tiles_y;
+  const int per_xcd = gridDim.x >> 3;
+  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= n_tiles) return; // whole workgroup leaves together (no barrier yet)
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lx = ((wave & 1) << 4) + (lane & 15);
+  const int ly = ((wave >> 1) << 2) + (lane >> 4);
+  const int w = tx * kTileW + lx;
+  // rows are produced top-down like main.cpp:628 (h = H-1 ... 0); tile row 0 = top of band
+  const int h = p.row_end - 1 - (ty * kTileH + ly);
+  const bool inside = (w < p.W) && (h >= p.row_begin);
+
+  // ---- main.cpp:709-713 + camera.h:31-34
+  const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
+  const float is = (float)w / (float)(p.W - 1);
+  const float it = (float)h / (float)(p.H - 1);
+  const f3 dir = normalize(((ld3(p.llc) + ld3(p.horizontal) * is) + ld3(p.vertical) * it) - origin);
+
+  // ---- main.cpp:722 closest hit over every primitive
+  Hit hit;
+  hit.t = FLT_MAX;
+  hit.v = 0.f;
+  hit.idx = -1;
+  if (STAGE == STAGE_SMEM) {
+    closest_tri_primary(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dir, hit);
+    closest_sph_primary(SmemFetch<DevSphP>{p.sph_p}, p.n_sph, p.n_tri, dir, hit);
+  } else {
+    constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTriP);
+    for (int k0 = 0; k0 < p.n_tri; k0 += CT) {
+      const int n = min(CT, p.n_tri - k0);
+      __syncthreads();
+      lds_stage(reinterpret_cast<DevTriP *>(lds_raw), p.tri_p + k0, n);
+      __syncthreads();
+      closest_tri_primary(LdsFetch<DevTriP>{reinterpret_cast<const DevTriP *>(lds_raw)}, n, k0,
+                          dir, hit);
+    }
+    constexpr int CS = kLdsChunkBytes / (int)sizeof(DevSphP);
+    for (int k0 = 0; k0 < p.n_sph; k0 += CS) {
+      const int n = min(CS, p.n_sph - k0);
+      __syncthreads();
+      lds_stage(reinterpret_cast<DevSphP *>(lds_raw), p.sph_p + k0, n);
+      __syncthreads();
+      closest_sph_primary(LdsFetch<DevSphP>{reinterpret_cast<const DevSphP *>(lds_raw)}, n,
+                          p.n_tri + k0, dir, hit);
+    }
+  }
+  const bool has_hit = inside && (hit.idx >= 0);
+
+  // ---- main.cpp:723-738 normal and material of the hit (per-lane gathers, once per pixel)
+  f3 N = mk(0.f, 0.f, 0.f);
+  f3 ka = N, kd = N, ks = N, ke = N;
+  float Ns = 0.f;
+  if (has_hit) {
+    int mi;
+    if (hit.idx < p.n_tri) {
+      const DevTri T = p.tri[hit.idx];
+      N = normalize(cross(ld3(T.e1), ld3(T.e2))); // :728-731
+      mi = T.geom;
+      if (p.mat[mi].has_normals) { // :733-738 with u == 0 (quirk S1)
+        const DevTriN Q = p.tri_n[hit.idx];
+        const float u = 0.f, v = hit.v;
+        N = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
+      }
+    } else {
+      const int k = hit.idx - p.n_tri;
+      const DevSph S = p.sph[k];
+      N = normalize((origin + dir * hit.t) - mk(S.cx, S.cy, S.cz)); // extension
+      mi = p.sph_mat[k];
+    }
+    const DevMat M = p.mat[mi];
+    ka = ld3(M.ka);
+    kd = ld3(M.kd);
+    ks = ld3(M.ks);
+    ke = ld3(M.ke);
+    Ns = M.Ns;
+  }
+
+  // ---- main.cpp:740-789 per-light shading
+  float r = 0.f, g = 0.f, b = 0.f; // vec3 default ctor, main.cpp:557-558
+  float t = hit.t;
+  const float nl = (float)p.n_lights;
+  uint32_t n_shadow = 0;
+  for (int li = 0; li < p.n_lights; ++li) {
+    const DevLight Lt = p.lights[li];
+    f3 hp = N, L = N;
+    float tb = 0.f, tocc = 0.f;
+    if (has_hit) {
+      uint32_t face = (p.face_mode == 0)
+                          ? (uint32_t)p.fixed_face
+                          : face_hash(p.seed, (uint32_t)(h * p.W + w), (uint32_t)li,
+                                      (uint32_t)Lt.n_faces);
+      const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
+      hp = origin + dir * (t - FLT_EPSILON); // :757-758
+      L = P - hp;                            // :759
+      const float len = length(L);           // :761
+      t = len - FLT_EPSILON;                 // :764
+      L = normalize(L);                      // :766
+      tb = t;
+    }
+    if (p.shadows) { // :772 occlusion(): wave-uniform loops, dead lanes carry tb = 0
+      if (!(tb > 0.f)) tb = 0.f;
+      n_shadow += has_hit ? 1u : 0u;
+      if (STAGE == STAGE_SMEM) {
+        if (__builtin_amdgcn_ballot_w64(tb > 0.f)) {
+          anyhit_tri(SmemFetch<DevTri>{p.tri}, p.n_tri, hp, L, tb, tocc);
+          anyhit_sph(SmemFetch<DevSph>{p.sph}, p.n_sph, hp, L, tb, tocc);
+        }
+      } else {
+        constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTri);
+        for (int k0 = 0; k0 < p.n_tri; k0 += CT) {
+          const int n = min(CT, p.n_tri - k0);
+          __syncthreads();
+          lds_stage(reinterpret_cast<DevTri *>(lds_raw), p.tri + k0, n);
+          __syncthreads();
+          anyhit_tri(LdsFetch<DevTri>{reinterpret_cast<const DevTri *>(lds_raw)}, n, hp, L, tb,
+                     tocc);
+        }
+        constexpr int CS = kLdsChunkBytes / (int)sizeof(DevSph);
+        for (int k0 = 0; k0 < p.n_sph; k0 += CS) {
+          const int n = min(CS, p.n_sph - k0);
+          __syncthreads();
+          lds_stage(reinterpret_cast<DevSph *>(lds_raw), p.sph + k0, n);
+          __syncthreads();
+          anyhit_sph(LdsFetch<DevSph>{reinterpret_cast<const DevSph *>(lds_raw)}, n, hp, L, tb,
+                     tocc);
+        }
+      }
+    }
+    if (has_hit) {
+      f3 c = (ka * 0.5f + ke) / nl; // :769-770
+      const bool occluded = p.shadows && (tocc != 0.f);
+      if (occluded) {
+        t = tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
+      } else {
+        const float d = dot(N, L); // :775
+        if (!(d <= 0.f)) {         // :777
+          const f3 Hh = normalize((N + L) * 2.f); // :780
+          const float sp = powf(dot(N, Hh), Ns);
+          c = c + (kd * d + ks * sp) / nl; // :782-783
+          r += c.x;                        // :786-788
+          g += c.y;
+          b += c.z;
+        }
+      }
+    }
+  }
+
+  // ---- counters: one atomic per wave (ballot + popcount)
+  if (p.counters) {
+    const uint64_t mi = __builtin_amdgcn_ballot_w64(inside);
+    const uint64_t mh = __builtin_amdgcn_ballot_w64(has_hit);
+    uint32_t ns = n_shadow;
+    for (int o = 32; o > 0; o >>= 1) ns += __shfl_down(ns, o);
+    if (lane == 0) {
+      atomicAdd(&p.counters[0], (unsigned long long)__popcll(mi));
+      atomicAdd(&p.counters[1], (unsigned long long)__popcll(mh));
+      atomicAdd(&p.counters[2], (unsigned long long)ns);
+    }
+  }
+
+  // ---- framebuffer: transpose the 32x8 tile through LDS so each store instruction writes
+  // consecutive dwords of one image row (12-byte pixels would otherwise stride the lanes).
+  const int w0 = tx * kTileW;
+  const int band_row0 = (p.row_end - 1 - ty * kTileH) - p.row_begin; // band-local row of ly = 0
+  const bool full_tile = (w0 + kTileW <= p.W) && (band_row0 - (kTileH - 1) >= 0);
+  if (p.out_f32) {
+    if (full_tile) {
+      const int li = (ly * kTileW + lx) * 3;
+      lds_px[li + 0] = r;
+      lds_px[li + 1] = g;
+      lds_px[li + 2] = b;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i; // 0..767
+        const int row = idx / (kTileW * 3), col = idx % (kTileW * 3);
+        const size_t o = ((size_t)(band_row0 - row) * p.W + w0) * 3 + col;
+        p.out_f32[o] = lds_px[idx];
+      }
+    } else if (inside) {
+      const size_t o = ((size_t)(h - p.row_begin) * p.W + w) * 3;
+      p.out_f32[o + 0] = r;
+      p.out_f32[o + 1] = g;
+      p.out_f32[o + 2] = b;
+    }
+  }
+  if (p.out_u8) { // main.cpp:676-682 clamp > 1, int(c * 255)
+    const float cr = (r > 1.f) ? 1.f : r, cg = (g > 1.f) ? 1.f : g, cb = (b > 1.f) ? 1.f : b;
+    const uint8_t qr = (uint8_t)(int)(cr * 255.f), qg = (uint8_t)(int)(cg * 255.f),
+                  qb = (uint8_t)(int)(cb * 255.f);
+    if (full_tile && (p.W & 3) == 0) {
+      __syncthreads(); // lds_px reuse
+      unsigned char *lb = reinterpret_cast<unsigned char *>(lds_px);
+      const int li = (ly * kTileW + lx) * 3;
+      lb[li + 0] = qr;
+      lb[li + 1] = qg;
+      lb[li + 2] = qb;
+      __syncthreads();
+      if (tid < kTileW * kTileH * 3 / 4) { // 192 dwords
+        const int row = tid / (kTileW * 3 / 4), col = tid % (kTileW * 3 / 4);
+        const size_t o = ((size_t)(band_row0 - row) * p.W + w0) * 3 + (size_t)col * 4;
+        *reinterpret_cast<uint32_t *>(p.out_u8 + o) = reinterpret_cast<const uint32_t *>(lb)[tid];
+      }
+    } else if (inside) {
+      const size_t o = ((size_t)(h - p.row_begin) * p.W + w) * 3;
+      p.out_u8[o + 0] = qr;
+      p.out_u8[o + 1] = qg;
+      p.out_u8[o + 2] = qb;
+    }
+  }
+}
+
+} // namespace esc
+
+// ---------------------------------------------------------------------------------------
+// host-side launchers (called from rt_capi.cpp)
+// ---------------------------------------------------------------------------------------
+extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
+                                  esc::DevSphP *sph_p, hipStream_t stream) {
+  const int n = p->n_tri > p->n_sph ? p->n_tri : p->n_sph;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
+                     tri_p, p->n_tri, p->sph, sph_p, p->n_sph, p->origin[0], p->origin[1],
+                     p->origin[2]);
+  return (int)hipGetLastError();
+}
+
+extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, hipStream_t stream) {
+  const int rows = p->row_end - p->row_begin;
+  if (rows <= 0 || p->W <= 0) return 0;
+  const int tiles_x = (p->W + esc::kTileW - 1) / esc::kTileW;
+  const int tiles_y = (rows + esc::kTileH - 1) / esc::kTileH;
+  const int n_tiles = tiles_x * tiles_y;
+  const int grid = ((n_tiles + 7) / 8) * 8;
+  if (stage == esc::STAGE_LDS)
+    hipLaunchKernelGGL(esc::k_render<esc::STAGE_LDS>, dim3(grid), dim3(256), 0, stream, *p);
+  else
+    hipLaunchKernelGGL(esc::k_render<esc::STAGE_SMEM>, dim3(grid), dim3(256), 0, stream, *p);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,254 @@
+/*
+ * esctp1_rt.h -- C ABI of the MI355X-native renderer that replaces the per-pixel render
+ * loop of pg42819/EscTp1RayTracer.
+ *
+ * Plain C: pointers, sizes and PODs only (no C++ / torch types), so the reference's
+ * C++ host (or any FFI: ctypes, cgo, JNI) can bind it.  Each entry point cites the
+ * reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - every function returning int returns ESC_OK (0) or a negative ESC_ERR_* code;
+ *     esc_last_error() gives the thread-local message.  No exception crosses this ABI
+ *     (the reference throws std::runtime_error, main.cpp:490-534, sceneloader.cpp:27-30).
+ *   - images are interleaved RGB, pixel (w,h) at index (h*W + w)*3, h = 0 is the BOTTOM
+ *     row (main.cpp:784-788 `image[h*W+w]`, flat form main.cpp:667-673).
+ *   - all host buffers are caller-owned; the library keeps no pointer after a call returns
+ *     unless stated.
+ *   - one esc_context per host thread / per GPU; calls on one context are not re-entrant.
+ */
+#ifndef ESCTP1_RT_H
+#define ESCTP1_RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  ESC_OK = 0,
+  ESC_ERR_INVALID = -1, /* bad argument / shape mismatch */
+  ESC_ERR_HIP = -2,     /* HIP runtime error (message carries hipGetErrorString) */
+  ESC_ERR_IO = -3,      /* file could not be opened / written */
+  ESC_ERR_PARSE = -4,   /* OBJ/MTL rejected (mirrors sceneloader.cpp:27-30,67-70 throws) */
+  ESC_ERR_NOMEM = -5,
+  ESC_ERR_NO_DEVICE = -6 /* no usable gfx950 device: the product has NO CPU fallback */
+};
+
+const char *esc_last_error(void);
+/* "esctp1raytracer_amd <ver> gfx950 hip" */
+const char *esc_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Host scene  == tracer::scene (src/scene/scene.h:8-44)
+ * ---------------------------------------------------------------------------------- */
+typedef struct esc_scene esc_scene;
+
+/* tracer::scene::Material, scene.h:11-18, as 13 floats: ka[3] kd[3] ks[3] ke[3] Ns */
+#define ESC_MATERIAL_FLOATS 13
+
+esc_scene *esc_scene_new(void);
+void esc_scene_free(esc_scene *scene);
+
+/* Append one tracer::scene::Geometry (scene.h:20-31): de-indexed vertices, optional
+ * per-vertex normals (n_normals == 0 => none), face_index triples into `vertex`.
+ * The geometry is a light source iff dot(ke,ke) > 0 (sceneloader.cpp:63-64,102-104).
+ * Returns the new geomID (>= 0) or a negative error. */
+int esc_scene_add_geometry(esc_scene *scene, const float *vertex, int32_t n_vertices,
+                           const float *normals, int32_t n_normals, const uint32_t *face_index,
+                           int32_t n_faces, const float material[ESC_MATERIAL_FLOATS]);
+
+/* EXTENSION (not in the reference): analytic spheres, cx cy cz r each,
+ * one material per sphere.  Tie order: after every triangle, then by sphere index. */
+int esc_scene_add_spheres(esc_scene *scene, const float *spheres_xyzr, const float *materials,
+                          int32_t n_spheres);
+
+/* model::loadobj (src/scene/sceneloader.h:10, sceneloader.cpp:14-106): OBJ + MTL ->
+ * one geometry per OBJ shape, vertices de-indexed 3 per face, material = first face's
+ * material, normals normalised on load.  Appends to `scene`. */
+int esc_scene_load_obj(esc_scene *scene, const char *obj_path);
+
+/* Synthetic scenes of BASELINE.json's configs (generator splitmix64):
+ *   "c2" 100 spheres, "c3" 1k spheres, "c4" 10k spheres, "c5" 100,352-triangle heightfield,
+ *   each with the 2-triangle floor and one single-triangle light.  n_override > 0 replaces
+ *   the primitive count (spheres, or heightfield quads per side for c5). */
+int esc_scene_synthetic(esc_scene *scene, const char *config, int32_t n_override);
+/* eye / look-at of the synthetic configs: (0,3,6) -> (0,2,-8) */
+void esc_synthetic_view(float eye[3], float look[3]);
+
+/* introspection (tests, bindings) */
+typedef struct {
+  int32_t n_geometry;
+  int32_t n_lights;
+  int32_t n_triangles; /* sum of faces */
+  int32_t n_spheres;
+} esc_scene_info;
+int esc_scene_get_info(const esc_scene *scene, esc_scene_info *info);
+/* counts[3] = n_vertices, n_normals, n_faces */
+int esc_scene_geometry_counts(const esc_scene *scene, int32_t geom, int32_t counts[3]);
+int esc_scene_geometry_copy(const esc_scene *scene, int32_t geom, float *vertex, float *normals,
+                            uint32_t *face_index, float material[ESC_MATERIAL_FLOATS]);
+int esc_scene_light_sources(const esc_scene *scene, int32_t *geom_ids /* [n_lights] */);
+int esc_scene_spheres_copy(const esc_scene *scene, float *spheres_xyzr, float *materials);
+
+/* ------------------------------------------------------------------------------------
+ * Camera == tracer::camera (src/scene/camera.h:7-41); ctor arithmetic runs on the host
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  float origin[3];
+  float lower_left_corner[3];
+  float horizontal[3];
+  float vertical[3];
+} esc_camera;
+
+/* camera.h:16-29.  aspect = float(W)/H at the call site (main.cpp:548). */
+void esc_camera_init(esc_camera *cam, const float lookfrom[3], const float lookat[3],
+                     const float vup[3], float vfov, float aspect);
+
+/* ------------------------------------------------------------------------------------
+ * ISPC-compatible flat scene == FlatScene (src/simplify/flatten_iscp.h:9-13) with the
+ * structs of src/ispc/ispc_helpers.h:16-48.  Layouts are byte-identical to what the
+ * ispc compiler emits into trace_ispc.h for those declarations.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ispc_triangle {
+  float vertices[3][3];
+  float normals[3][3];
+  int32_t prim_id;
+  int32_t geom_id;
+  int32_t has_normals;
+  int32_t is_light;
+  float ka[3];
+  float kd[3];
+  float ks[3];
+  float ke[3];
+  float Ns;
+} ispc_triangle; /* 140 bytes */
+
+typedef struct ispc_light {
+  int32_t geom_id;
+  int32_t *light_faces; /* indexes into light_triangles[] */
+  int32_t num_light_faces;
+} ispc_light; /* 24 bytes on LP64 */
+
+typedef struct ispc_cam {
+  float lookfrom[3];
+  float lookat[3];
+  float vup[3];
+  float vfov;
+  float aspect;
+} ispc_cam; /* 44 bytes */
+
+typedef struct esc_flat_scene esc_flat_scene;
+/* flatten_scene_ispc (flatten_iscp.cpp:35-111).  sort_by_centroid_x != 0 reproduces the
+ * reference's std::sort at flatten_iscp.cpp:110 (it changes tie order vs the scalar path);
+ * 0 keeps (geometry, face) order == the scalar path's order.  Unlike the reference
+ * (dangling vector, defect I4) the light_faces arrays stay valid until esc_flat_free. */
+int esc_flatten_ispc(const esc_scene *scene, int32_t sort_by_centroid_x, esc_flat_scene **out);
+void esc_flat_free(esc_flat_scene *flat);
+ispc_triangle *esc_flat_triangles(esc_flat_scene *flat, int32_t *n);
+ispc_triangle *esc_flat_light_triangles(esc_flat_scene *flat, int32_t *n);
+ispc_light *esc_flat_lights(esc_flat_scene *flat, int32_t *n);
+/* new_ispc_cam (flatten_iscp.cpp:117-128) */
+void esc_new_ispc_cam(ispc_cam *cam, const float lookfrom[3], const float lookat[3],
+                      const float vup[3], float vfov, float aspect);
+
+/* ------------------------------------------------------------------------------------
+ * THE DROP-IN: same symbol, argument list and image convention as the ISPC export
+ *   src/ispc/trace.ispc:86-92, called at src/main.cpp:619-624
+ * (the generated header declares it `extern "C"` inside namespace ispc with `ispc_cam &`;
+ * a C++ reference is a pointer in the C ABI).  Semantics = the reference's SCALAR path
+ * (main.cpp:698-791) on the flat arrays in the order given; the image is OVERWRITTEN (the
+ * reference accumulates into uninitialised memory, defect I3).  Synchronous; renders on
+ * device 0 (or $ESC_DEVICE); errors are reported on stderr and leave the image zeroed,
+ * because the replaced function returns void.  Multi-face lights use the counter-based
+ * face choice below with seed 0.
+ * ---------------------------------------------------------------------------------- */
+void trace(int32_t image_width, int32_t image_height, ispc_cam *cam, int32_t num_triangles,
+           ispc_triangle triangles[], int32_t num_lights, ispc_light lights[],
+           int32_t num_light_triangles, ispc_triangle light_triangles[], float *return_image,
+           int32_t debug, int32_t test);
+
+/* ------------------------------------------------------------------------------------
+ * Extended entry points (persistent device state, row bands, device-resident output)
+ * ---------------------------------------------------------------------------------- */
+typedef struct esc_context esc_context;
+
+enum {
+  ESC_FACE_FIXED = 0, /* faceID = fixed_face: the reference's behaviour for 1-face lights */
+  ESC_FACE_HASH = 1   /* faceID = splitmix64(seed,pixel,light) % n_faces; replaces the
+                         std::random_device-seeded mt19937 draw of main.cpp:587-588,743-747 */
+};
+
+enum {
+  ESC_STAGE_AUTO = 0, /* fastest measured variant per pass */
+  ESC_STAGE_SMEM = 1, /* primitives broadcast through the scalar cache into SGPRs */
+  ESC_STAGE_LDS = 2   /* primitives staged in LDS chunks by the workgroup */
+};
+
+typedef struct {
+  int32_t shadows;   /* 1 = occlusion() evaluated (main.cpp:772); 0 = "primary rays only" */
+  int32_t face_mode; /* ESC_FACE_* */
+  int32_t fixed_face;
+  int32_t stage; /* ESC_STAGE_* */
+  uint64_t seed;
+} esc_render_options;
+
+typedef struct {
+  uint64_t primary_rays;
+  uint64_t hit_pixels;
+  uint64_t shadow_rays;
+} esc_counters;
+
+/* Creates a context on HIP device `device` with its own stream.  Fails with
+ * ESC_ERR_NO_DEVICE when there is no GPU: there is no CPU fallback. */
+int esc_context_create(int32_t device, esc_context **out);
+void esc_context_destroy(esc_context *ctx);
+/* Launch on the caller's hipStream_t instead (e.g. a torch stream's handle). */
+int esc_context_set_stream(esc_context *ctx, void *hip_stream);
+void *esc_context_stream(esc_context *ctx);
+int esc_context_synchronize(esc_context *ctx);
+
+/* == flatten + hipMemcpy: stages the scene as SoA tables in HBM (replaces
+ * flatten_scene_ispc's role at main.cpp:591-605).  Re-upload replaces the previous one. */
+int esc_upload_scene(esc_context *ctx, const esc_scene *scene);
+/* same, from ISPC flat arrays (what trace() does internally) */
+int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle *triangles,
+                    int32_t num_lights, const ispc_light *lights, int32_t num_light_triangles,
+                    const ispc_triangle *light_triangles);
+
+/* == the row loop main.cpp:628-636 restricted to rows [row_begin,row_end) of a W x H frame
+ * (scan_row, main.cpp:28-30, is the row-granular seam).  Asynchronous on the context's
+ * stream.  Outputs are DEVICE pointers, band-local: pixel (w,h) at ((h-row_begin)*W+w)*3.
+ *   d_rgb_f32  fp32 RGB accumulators (may be NULL)
+ *   d_rgb_u8   8-bit RGB after the PPM clamp/truncate of main.cpp:676-682 (may be NULL)
+ * Counters accumulate on the device; read them with esc_read_counters (synchronises). */
+int esc_render_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
+                    int32_t row_begin, int32_t row_end, const esc_render_options *opts,
+                    float *d_rgb_f32, uint8_t *d_rgb_u8);
+int esc_reset_counters(esc_context *ctx);
+int esc_read_counters(esc_context *ctx, esc_counters *out);
+
+/* Whole frame into HOST memory, synchronous: render + D2H.  `image` = W*H*3 floats. */
+int esc_render_frame_host(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
+                          const esc_render_options *opts, float *image, uint8_t *rgb8);
+
+/* Single-process multi-GPU: rows split into n_devices contiguous bands (H/n each, the
+ * remainder to the last), each rendered on its own device concurrently, bands gathered
+ * into the caller's host buffers.  (bench.py uses one process per GPU + RCCL instead.) */
+int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_t W, int32_t H,
+                           const esc_render_options *opts, int32_t n_devices, float *image,
+                           uint8_t *rgb8, float *ms_per_device /* [n_devices] or NULL */);
+
+/* ------------------------------------------------------------------------------------
+ * PPM writer == main.cpp:658-689: "P3\nW H\n255\n", rows top-down, clamp >1, int(c*255)
+ * ---------------------------------------------------------------------------------- */
+int esc_write_ppm(const char *path, const float *image, int32_t W, int32_t H);
+/* same text from already-quantised bytes (same (h*W+w)*3 order) */
+int esc_write_ppm_u8(const char *path, const uint8_t *rgb8, int32_t W, int32_t H);
+void esc_quantise(const float *image, int64_t n_values, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESCTP1_RT_H */
