@@ -11,7 +11,7 @@ LIB      := $(LIBDIR)/libesctp1rt.so
 VIEWER   := bin/ESCViewer2021
 
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
-            -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
+            -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize \
             -Iinclude -I$(PKG)/host -I$(PKG)/csrc -Wall -Wno-unused-function
 
 LIB_SRC  := $(PKG)/csrc/rt_kernels.hip $(PKG)/csrc/rt_capi.cpp \

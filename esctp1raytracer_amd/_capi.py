@@ -132,6 +132,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7 and preloads it by
+    # path.  If ours (resolved to /opt/rocm) is loaded first the process ends up with two
+    # runtimes and the second one sees no GPU.  Loading torch first makes our NEEDED entry bind
+    # to the copy torch already mapped.  (The C++ viewer has no torch and uses /opt/rocm's.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make lib` (or __graft_entry__.build()); "

@@ -146,39 +146,65 @@ struct Hit {
   int32_t idx; // -1 none; [0,n_tri) triangle; n_tri + k sphere k
 };
 
-// closest hit, primary rays, triangles [k0, k0+n)
-template <typename Fetch>
-DEVINL void closest_tri_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
-  int k = 0;
-  for (; k + 2 <= n; k += 2) {
-    const DevTriP A = rec(k), B = rec(k + 1);
-    const f3 pa = cross(d, ld3(A.e2)), pb = cross(d, ld3(B.e2)); // ray_triangle.h:18
-    const float da = dot(ld3(A.e1), pa), db = dot(ld3(B.e1), pb); // :21
-    const float ua = dot(ld3(A.tv), pa), ub = dot(ld3(B.tv), pb); // :32 numerator
-    const float va = dot(d, ld3(A.qv)), vb = dot(d, ld3(B.qv));   // :40 numerator
-    const bool ca = tri_candidate(da, ua, va), cb = tri_candidate(db, ub, vb);
-    if (__builtin_amdgcn_ballot_w64(ca | cb)) { // wave-uniform skip of the f64 tail
-      float t2, v2;
-      if (ca && tri_exact(da, ua, va, A.tnum, h.t, t2, v2)) {
-        h.t = t2;
-        h.v = v2;
-        h.idx = base + k;
-      }
-      if (cb && tri_exact(db, ub, vb, B.tnum, h.t, t2, v2)) {
-        h.t = t2;
-        h.v = v2;
-        h.idx = base + k + 1;
-      }
+// Every loop below is software-pipelined by hand: the records of the NEXT batch are fetched
+// (s_load_dwordx8/x16, or ds_read_b128) before the current batch is tested, in two
+// alternating register sets, so a wave never waits on the fetch it just issued.
+
+template <typename Rec, int B, typename Fetch>
+DEVINL void fetch_batch(Fetch rec, int k, Rec (&r)[B]) {
+#pragma unroll
+  for (int i = 0; i < B; ++i) r[i] = rec(k + i);
+  // hipcc's scheduler otherwise sinks the fetch to just above its first use (measured in the
+  // ISA: the s_load landed 4 instructions before the s_waitcnt); pin it where it is written.
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- closest hit, primary rays, triangles ------------------------------------------------
+DEVINL void tri_primary_numerators(const DevTriP &T, f3 d, float &det, float &un, float &vn) {
+  const f3 pv = cross(d, ld3(T.e2)); // ray_triangle.h:18
+  det = dot(ld3(T.e1), pv);          // :21
+  un = dot(ld3(T.tv), pv);           // :32 numerator
+  vn = dot(d, ld3(T.qv));            // :40 numerator
+}
+
+DEVINL void test_tri2_primary(const DevTriP (&T)[2], int idx, f3 d, Hit &h) {
+  float da, ua, va, db, ub, vb;
+  tri_primary_numerators(T[0], d, da, ua, va);
+  tri_primary_numerators(T[1], d, db, ub, vb);
+  const bool ca = tri_candidate(da, ua, va), cb = tri_candidate(db, ub, vb);
+  if (__builtin_amdgcn_ballot_w64(ca | cb)) { // wave-uniform skip of the f64 tail
+    float t2, v2;
+    if (ca && tri_exact(da, ua, va, T[0].tnum, h.t, t2, v2)) {
+      h.t = t2;
+      h.v = v2;
+      h.idx = idx;
+    }
+    if (cb && tri_exact(db, ub, vb, T[1].tnum, h.t, t2, v2)) {
+      h.t = t2;
+      h.v = v2;
+      h.idx = idx + 1;
     }
   }
-  for (; k < n; ++k) {
-    const DevTriP A = rec(k);
-    const f3 pa = cross(d, ld3(A.e2));
-    const float da = dot(ld3(A.e1), pa);
-    const float ua = dot(ld3(A.tv), pa);
-    const float va = dot(d, ld3(A.qv));
-    float t2, v2;
-    if (tri_candidate(da, ua, va) && tri_exact(da, ua, va, A.tnum, h.t, t2, v2)) {
+}
+
+template <typename Fetch>
+DEVINL void closest_tri_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
+  const int n4 = n & ~3;
+  if (n4) {
+    DevTriP A[2], B[2];
+    fetch_batch(rec, 0, A);
+    for (int k = 0; k < n4; k += 4) {
+      fetch_batch(rec, rec.landed(A[1].tnum, k + 2), B);
+      test_tri2_primary(A, base + k, d, h);
+      fetch_batch(rec, rec.landed(B[1].tnum, min(k + 4, n - 2)), A); // clamped: last one unused
+      test_tri2_primary(B, base + k + 2, d, h);
+    }
+  }
+  for (int k = n4; k < n; ++k) {
+    const DevTriP T = rec(k);
+    float da, ua, va, t2, v2;
+    tri_primary_numerators(T, d, da, ua, va);
+    if (tri_candidate(da, ua, va) && tri_exact(da, ua, va, T.tnum, h.t, t2, v2)) {
       h.t = t2;
       h.v = v2;
       h.idx = base + k;
@@ -186,87 +212,138 @@ DEVINL void closest_tri_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
   }
 }
 
-// closest hit, primary rays, spheres
-template <typename Fetch>
-DEVINL void closest_sph_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
-  int k = 0;
-  for (; k + 4 <= n; k += 4) {
-    const DevSphP s0 = rec(k), s1 = rec(k + 1), s2 = rec(k + 2), s3 = rec(k + 3);
-    const float b0 = (s0.ocx * d.x + s0.ocy * d.y) + s0.ocz * d.z;
-    const float b1 = (s1.ocx * d.x + s1.ocy * d.y) + s1.ocz * d.z;
-    const float b2 = (s2.ocx * d.x + s2.ocy * d.y) + s2.ocz * d.z;
-    const float b3 = (s3.ocx * d.x + s3.ocy * d.y) + s3.ocz * d.z;
-    const float q0 = b0 * b0 - s0.cc, q1 = b1 * b1 - s1.cc;
-    const float q2 = b2 * b2 - s2.cc, q3 = b3 * b3 - s3.cc;
-    const float m = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
-    if (__builtin_amdgcn_ballot_w64(!(m < 0.f))) {
+// ---- closest hit, primary rays, spheres ---------------------------------------------------
+DEVINL void test_sph4_primary(const DevSphP (&s)[4], int idx, f3 d, Hit &h) {
+  float b[4], q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b[i] = (s[i].ocx * d.x + s[i].ocy * d.y) + s[i].ocz * d.z;
+    q[i] = b[i] * b[i] - s[i].cc;
+  }
+  const float m = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
+  if (__builtin_amdgcn_ballot_w64(!(m < 0.f))) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
       float t2;
-      if (sph_exact(b0, q0, h.t, t2)) { h.t = t2; h.idx = base + k; }
-      if (sph_exact(b1, q1, h.t, t2)) { h.t = t2; h.idx = base + k + 1; }
-      if (sph_exact(b2, q2, h.t, t2)) { h.t = t2; h.idx = base + k + 2; }
-      if (sph_exact(b3, q3, h.t, t2)) { h.t = t2; h.idx = base + k + 3; }
-    }
-  }
-  for (; k < n; ++k) {
-    const DevSphP s0 = rec(k);
-    const float b0 = (s0.ocx * d.x + s0.ocy * d.y) + s0.ocz * d.z;
-    const float q0 = b0 * b0 - s0.cc;
-    float t2;
-    if (sph_exact(b0, q0, h.t, t2)) { h.t = t2; h.idx = base + k; }
-  }
-}
-
-// any-hit (main.cpp:314-329), general origin.  tb = per-lane bound: > 0 while the lane is
-// still looking, set to 0 once it found its FIRST occluder (or if it never looked), so later
-// primitives cannot accept (accepts need eps <= t2 < tb).  tocc receives that occluder's t2
-// (occlusion() mutates the caller's t, quirk S3).
-template <typename Fetch>
-DEVINL void anyhit_tri(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
-  for (int k = 0; k < n; ++k) {
-    if ((k & 3) == 0 && !__builtin_amdgcn_ballot_w64(tb > 0.f)) return; // every lane done
-    const DevTri T = rec(k);
-    const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
-    const f3 pv = cross(L, e2);          // ray_triangle.h:18
-    const float det = dot(e1, pv);       // :21
-    const f3 tv = o - ld3(T.v0);         // :29
-    const float un = dot(tv, pv);        // :32
-    const f3 qv = cross(tv, e1);         // :37
-    const float vn = dot(L, qv);         // :40
-    const bool c = tri_candidate(det, un, vn);
-    if (__builtin_amdgcn_ballot_w64(c)) {
-      float t2, v2;
-      if (c && tri_exact(det, un, vn, dot(e2, qv), tb, t2, v2)) {
-        tocc = t2;
-        tb = 0.f;
+      if (sph_exact(b[i], q[i], h.t, t2)) {
+        h.t = t2;
+        h.idx = idx + i;
       }
     }
   }
 }
 
 template <typename Fetch>
-DEVINL void anyhit_sph(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
-  int k = 0;
-  for (; k + 2 <= n; k += 2) {
-    if ((k & 7) == 0 && !__builtin_amdgcn_ballot_w64(tb > 0.f)) return;
-    const DevSph s0 = rec(k), s1 = rec(k + 1);
-    const f3 oc0 = mk(o.x - s0.cx, o.y - s0.cy, o.z - s0.cz);
-    const f3 oc1 = mk(o.x - s1.cx, o.y - s1.cy, o.z - s1.cz);
-    const float b0 = dot(oc0, L), b1 = dot(oc1, L);
-    const float c0 = dot(oc0, oc0) - s0.r2, c1 = dot(oc1, oc1) - s1.r2;
-    const float q0 = b0 * b0 - c0, q1 = b1 * b1 - c1;
-    if (__builtin_amdgcn_ballot_w64(!(fmaxf(q0, q1) < 0.f))) {
-      float t2;
-      if (sph_exact(b0, q0, tb, t2)) { tocc = t2; tb = 0.f; }
-      if (sph_exact(b1, q1, tb, t2)) { tocc = t2; tb = 0.f; }
+DEVINL void closest_sph_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
+  const int n8 = n & ~7;
+  if (n8) {
+    DevSphP A[4], B[4];
+    fetch_batch(rec, 0, A);
+    for (int k = 0; k < n8; k += 8) {
+      fetch_batch(rec, rec.landed(A[3].cc, k + 4), B);
+      test_sph4_primary(A, base + k, d, h);
+      fetch_batch(rec, rec.landed(B[3].cc, min(k + 8, n - 4)), A);
+      test_sph4_primary(B, base + k + 4, d, h);
     }
   }
-  for (; k < n; ++k) {
-    const DevSph s0 = rec(k);
-    const f3 oc0 = mk(o.x - s0.cx, o.y - s0.cy, o.z - s0.cz);
-    const float b0 = dot(oc0, L);
-    const float q0 = b0 * b0 - (dot(oc0, oc0) - s0.r2);
+  for (int k = n8; k < n; ++k) {
+    const DevSphP s0 = rec(k);
+    const float b0 = (s0.ocx * d.x + s0.ocy * d.y) + s0.ocz * d.z;
+    const float q0 = b0 * b0 - s0.cc;
     float t2;
-    if (sph_exact(b0, q0, tb, t2)) { tocc = t2; tb = 0.f; }
+    if (sph_exact(b0, q0, h.t, t2)) {
+      h.t = t2;
+      h.idx = base + k;
+    }
+  }
+}
+
+// ---- any-hit (main.cpp:314-329), general origin -------------------------------------------
+// tb = per-lane bound: > 0 while the lane is still looking, set to 0 once it found its FIRST
+// occluder (or if it never looked), so later primitives cannot accept (accepts need
+// eps <= t2 < tb).  tocc receives that occluder's t2 (occlusion() mutates the caller's t,
+// quirk S3).  The wave leaves a loop early once no lane is looking (checked per block of
+// kExitStride primitives, not per primitive).
+constexpr int kExitStride = 32;
+
+DEVINL void test_tri_any(const DevTri &T, f3 o, f3 L, float &tb, float &tocc) {
+  const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+  const f3 pv = cross(L, e2);    // ray_triangle.h:18
+  const float det = dot(e1, pv); // :21
+  const f3 tv = o - ld3(T.v0);   // :29
+  const float un = dot(tv, pv);  // :32
+  const f3 qv = cross(tv, e1);   // :37
+  const float vn = dot(L, qv);   // :40
+  const bool c = tri_candidate(det, un, vn);
+  if (__builtin_amdgcn_ballot_w64(c)) {
+    float t2, v2;
+    if (c && tri_exact(det, un, vn, dot(e2, qv), tb, t2, v2)) {
+      tocc = t2;
+      tb = 0.f;
+    }
+  }
+}
+
+template <typename Fetch>
+DEVINL void anyhit_tri(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
+  for (int k0 = 0; k0 < n; k0 += kExitStride) {
+    if (!__builtin_amdgcn_ballot_w64(tb > 0.f)) return; // every lane done
+    const int m = min(kExitStride, n - k0);
+    const int m2 = m & ~1;
+    if (m2) {
+      DevTri A = rec(k0), B;
+      for (int k = 0; k < m2; k += 2) {
+        B = rec(rec.landed(A.e2[2], k0 + k + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        test_tri_any(A, o, L, tb, tocc);
+        A = rec(rec.landed(B.e2[2], k0 + min(k + 2, m - 1)));
+        __builtin_amdgcn_sched_barrier(0);
+        test_tri_any(B, o, L, tb, tocc);
+      }
+    }
+    if (m2 < m) test_tri_any(rec(k0 + m2), o, L, tb, tocc);
+  }
+}
+
+DEVINL void test_sph2_any(const DevSph (&s)[2], f3 o, f3 L, float &tb, float &tocc) {
+  float b[2], q[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f3 oc = mk(o.x - s[i].cx, o.y - s[i].cy, o.z - s[i].cz);
+    b[i] = dot(oc, L);
+    q[i] = b[i] * b[i] - (dot(oc, oc) - s[i].r2);
+  }
+  if (__builtin_amdgcn_ballot_w64(!(fmaxf(q[0], q[1]) < 0.f))) {
+    float t2;
+    if (sph_exact(b[0], q[0], tb, t2)) { tocc = t2; tb = 0.f; }
+    if (sph_exact(b[1], q[1], tb, t2)) { tocc = t2; tb = 0.f; }
+  }
+}
+
+template <typename Fetch>
+DEVINL void anyhit_sph(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
+  for (int k0 = 0; k0 < n; k0 += kExitStride) {
+    if (!__builtin_amdgcn_ballot_w64(tb > 0.f)) return;
+    const int m = min(kExitStride, n - k0);
+    const int m4 = m & ~3;
+    if (m4) {
+      DevSph A[2], B[2];
+      fetch_batch(rec, k0, A);
+      for (int k = 0; k < m4; k += 4) {
+        fetch_batch(rec, rec.landed(A[1].r2, k0 + k + 2), B);
+        test_sph2_any(A, o, L, tb, tocc);
+        fetch_batch(rec, rec.landed(B[1].r2, k0 + min(k + 4, m - 2)), A);
+        test_sph2_any(B, o, L, tb, tocc);
+      }
+    }
+    for (int k = m4; k < m; ++k) {
+      const DevSph s0 = rec(k0 + k);
+      const f3 oc = mk(o.x - s0.cx, o.y - s0.cy, o.z - s0.cz);
+      const float b0 = dot(oc, L);
+      const float q0 = b0 * b0 - (dot(oc, oc) - s0.r2);
+      float t2;
+      if (sph_exact(b0, q0, tb, t2)) { tocc = t2; tb = 0.f; }
+    }
   }
 }
 
@@ -279,6 +356,17 @@ DEVINL void anyhit_sph(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
 template <typename Rec> struct SmemFetch {
   const Rec *__restrict__ p;
   DEVINL Rec operator()(int k) const { return p[k]; }
+  // Scalar loads return out of order, so the only wait hipcc can emit is lgkmcnt(0).  Naming
+  // one SGPR of the previous batch in an empty asm makes that wait land HERE, before the next
+  // batch's s_load is issued, instead of behind it.
+  // (Not `volatile`, no memory clobber: a side-effecting asm makes hipcc give up proving the
+  // tables are never written and it falls back from s_load to per-lane global_load.)
+  // The index of the next fetch is threaded through the same asm so the s_load cannot be
+  // hoisted above it.
+  DEVINL int landed(float &x, int next_k) const {
+    asm("" : "+s"(x), "+s"(next_k));
+    return next_k;
+  }
 };
 
 // LDS: the workgroup copies a chunk of the table into LDS (16 B per lane per step,
@@ -286,6 +374,7 @@ template <typename Rec> struct SmemFetch {
 template <typename Rec> struct LdsFetch {
   const Rec *p;
   DEVINL Rec operator()(int k) const { return p[k]; }
+  DEVINL int landed(float &, int next_k) const { return next_k; } // ds_read is in order
 };
 
 template <typename Rec>

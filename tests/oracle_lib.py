@@ -320,3 +320,19 @@ def scene_two():
     v, fi, _ = _tris(p, [(11, 12, 13)])
     g.append({"vertex": v, "face_index": fi, "material": LIGHT_B})
     return scene_dict(g)
+
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def load_dump(name_or_path):
+    """tests/golden/loader_<name>.npz (what the reference's model::loadobj returned) -> dict"""
+    path = name_or_path if os.path.exists(name_or_path) else \
+        os.path.join(GOLDEN_DIR, f"loader_{name_or_path}.npz")
+    z = np.load(path)
+    geometry = [{"vertex": z[f"g{g}_vertex"], "normals": z[f"g{g}_normals"],
+                 "face_index": z[f"g{g}_face_index"], "material": z[f"g{g}_material"]}
+                for g in range(int(z["n_geometry"]))]
+    d = scene_dict(geometry)
+    assert d["light_sources"] == list(z["light_sources"])
+    return d
