@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of the workload BASELINE.json's metric is quoted on (config c4):
+3840x2160, 10,000 random spheres + a 2-triangle floor + one single-triangle light, one primary
+ray per pixel and one shadow ray per hit pixel, brute force, scene resident in HBM.  With N
+ranks the frame is cut into 8-row strips dealt round-robin (esctp1raytracer_amd/multigpu.py),
+each rank renders its strips with k_render and the fp32 framebuffer is gathered to rank 0 over
+RCCL and laid out as one frame there; total work is fixed, so scaling is "strong".
+
+Rank 0 prints ONE JSON line.  `value` = rays of all ranks / wall time (max over ranks) in
+Mrays/s; rays = primary (W*H) + shadow (hit pixels x lights), counted by the kernel itself.
+`roofline` is the HBM view north_star asks for (algorithmic bytes / measured kernel time vs
+8 TB/s) and `roofline_valu` the view that actually bounds this kernel.
+`cpu_baseline` times the test oracle (oracle/rt_oracle.c, a strict-IEEE restatement of the
+reference's scalar path: the reference's ISPC path cannot be built, `ispc` is not in the image)
+on a bounded sample of rows of the SAME frame on all host cores, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import esctp1raytracer_amd as esc  # noqa: E402
+from esctp1raytracer_amd import multigpu  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec)
+FP32_VALU_PEAK_TF = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
+F_SPHERE, F_TRI = 19, 51   # algorithmic flop per ray-primitive test, SURVEY.md 8(d)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", help="c2|c3|c4|c5 (BASELINE.json configs 2-5)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--prims", type=int, default=0, help="override primitive count (0 = config's)")
+    ap.add_argument("--stage", default="auto", choices=["auto", "smem", "lds"])
+    ap.add_argument("--gather", default="f32", choices=["f32", "u8"],
+                    help="what rank 0 collects: fp32 RGB (the seam's return_image) or PPM bytes")
+    ap.add_argument("--cpu-rows", type=int, default=128,
+                    help="rows of the frame the CPU baseline renders (0 = skip)")
+    return ap.parse_args()
+
+
+CONFIGS = {  # BASELINE.json configs 2-5 -> (W, H, shadows)
+    "c2": (1920, 1080, False),
+    "c3": (3840, 2160, True),
+    "c4": (3840, 2160, True),
+    "c5": (7680, 4320, True),
+}
+
+
+def cpu_baseline(scene, eye, look, W, H, shadows, n_rows, gpu_frame):
+    """oracle on evenly spaced rows of the same frame, all host cores; also a free parity
+    spot-check of the GPU frame on those rows"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+
+    import oracle_lib as ol
+
+    d = ol.OracleScene(ol.scene_from_product(scene))
+    rows = sorted({min(H - 1, int((i + 0.5) * H / n_rows)) for i in range(n_rows)})
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    img, cnt = ol.oracle_render_rows(d, eye, look, W, H, rows, shadows=shadows, threads=cores)
+    dt = time.perf_counter() - t0
+    rays = cnt["primary_rays"] + cnt["shadow_rays"]
+    same = None
+    if gpu_frame is not None:
+        g = gpu_frame[rows]
+        same = bool(np.array_equal(g.view(np.uint32), img.view(np.uint32)))
+    return {
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"{len(rows)} evenly spaced rows of the same {W}x{H} frame "
+                  f"({rays} rays, {dt:.1f} s); oracle/rt_oracle.c, gcc -O2 -ffp-contract=off, "
+                  f"row-parallel pthreads",
+        "seconds": dt,
+    }, same
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch through "
+              f"torch.distributed.run for N>1", file=sys.stderr)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the renderer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W0, H0, shadows = CONFIGS[a.config]
+    W, H = a.width or W0, a.height or H0
+    scene = esc.Scene.synthetic(a.config, a.prims)
+    info = scene.info()
+    eye, look = esc.synthetic_view()
+    cam = esc.Camera.for_image(eye, look, W, H)
+    stage = {"auto": esc.ESC_STAGE_AUTO, "smem": esc.ESC_STAGE_SMEM, "lds": esc.ESC_STAGE_LDS}[a.stage]
+
+    st = torch.cuda.Stream(device=dev)
+    r = esc.Renderer(local_rank, stream=st)
+    r.upload(scene)  # scene resident in HBM before any timed region
+
+    S = multigpu.STRIP_ROWS
+    my_rows = multigpu.local_rows(H, rank, world, S)
+    max_rows = multigpu.max_local_rows(H, world, S)
+    use_u8 = a.gather == "u8"
+    ch_dtype = torch.uint8 if use_u8 else torch.float32
+    local = torch.zeros(max_rows * W * 3, dtype=ch_dtype, device=dev)
+    gathered = frame = None
+    if world > 1 and rank == 0:
+        gathered = torch.zeros(world, max_rows * W * 3, dtype=ch_dtype, device=dev)
+        frame = torch.zeros(H * W * 3, dtype=ch_dtype, device=dev)
+
+    events = []
+
+    def step(timed):
+        with torch.cuda.stream(st):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            r.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local,
+                            out_u8=local if use_u8 else None, strip_rows=S, shadows=shadows,
+                            stage=stage)
+            e1.record(st)
+            if timed:
+                events.append((e0, e1))
+            if world > 1:
+                multigpu.gather_to_root(local, rank, world, gathered)
+                if rank == 0:
+                    r.assemble_strips(gathered, world, max_rows * W * 3 * local.element_size(), W,
+                                      H, frame, strip_rows=S, bytes_per_pixel=3 * local.element_size())
+
+    def fence():
+        st.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    fence()
+    r.reset_counters()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    cnt = r.counters()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    c = torch.tensor([cnt["primary_rays"], cnt["shadow_rays"], cnt["anyhit_tests"],
+                      cnt["hit_pixels"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    primary, shadow, anyhit, hits = (float(x) for x in c.tolist())
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
+
+    if rank == 0:
+        rays = primary + shadow
+        n_tri, n_sph = info["n_triangles"], info["n_spheres"]
+        # ---- roofline of the dominant kernel (k_render) on THIS rank's launch
+        frame_bytes = my_rows * W * 3 * local.element_size()
+        scene_bytes = n_sph * 32 + n_tri * 112 + (info["n_geometry"] + n_sph) * 64
+        alg_bytes = frame_bytes + scene_bytes
+        gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if world == 1 and a.config == "c4" and not a.prims and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        share = my_rows / H
+        closest_flop = (primary / a.steps) * share * (n_tri * F_TRI + n_sph * F_SPHERE)
+        f_any = (n_tri * F_TRI + n_sph * F_SPHERE) / max(n_tri + n_sph, 1)
+        anyhit_flop = (anyhit / a.steps) * share * f_any
+        tf = (closest_flop + anyhit_flop) / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/sec + frame ms, 3840x2160 / 10k spheres, at 1/2/4/8 MI355X",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{a.config}: {W}x{H}, {n_sph} spheres + {n_tri} triangles, "
+                            f"{info['n_lights']} light, 1 primary ray/pixel + "
+                            f"{'1 shadow ray per hit pixel' if shadows else 'no shadow rays'}, "
+                            f"brute force",
+                "scene": "esc_scene_synthetic (SURVEY.md 8(d)): splitmix64 seeds 0xC2..0xC4",
+                "partition": f"{S}-row strips round-robin over {world} rank(s)",
+                "gather": ("none (1 GPU)" if world == 1 else
+                           f"RCCL gather of {'u8' if use_u8 else 'fp32'} RGB strips to rank 0 "
+                           f"+ k_assemble_strips"),
+                "stage": a.stage,
+                "rays_per_frame": rays / a.steps,
+                "primary_rays_per_frame": primary / a.steps,
+                "shadow_rays_per_frame": shadow / a.steps,
+                "hit_pixels_per_frame": hits / a.steps,
+            },
+            "kernel": {"name": "k_render", "avg_ms": kernel_ms,
+                       "launches_timed": len(events), "rank": 0, "rows": my_rows},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline_valu": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TF,
+                              "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
+                              "note": "algorithmic flop (19/sphere test, 51/triangle test) of the "
+                                      "tests the reference executes / kernel time; the peak counts "
+                                      "FMA as 2 flop and this kernel may not fuse (bit parity), so "
+                                      "0.5 is the ceiling"},
+        }
+        if world == 1 and a.cpu_rows > 0:
+            gpu_frame = None
+            if not use_u8:
+                gpu_frame = local[:H * W * 3].cpu().numpy().reshape(H, W, 3)
+            cb, same = cpu_baseline(scene, eye, look, W, H, shadows, a.cpu_rows, gpu_frame)
+            out["cpu_baseline"] = cb
+            out["gpu_vs_cpu"] = out["value"] / cb["value"]
+            out["parity_sample_rows_bit_exact"] = same
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ from . import _capi
 from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_LDS,
                     ESC_STAGE_SMEM, EscError, check)
 
-__all__ = ["Scene", "Camera", "Renderer", "trace", "write_ppm", "quantise", "synthetic_view",
+__all__ = ["Scene", "Camera", "Renderer", "FlatScene", "render_multi", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
            "EscError", "ESC_FACE_FIXED", "ESC_FACE_HASH", "ESC_STAGE_AUTO", "ESC_STAGE_SMEM",
            "ESC_STAGE_LDS", "version"]
 
@@ -246,6 +246,39 @@ class Renderer:
         check(self._lib.esc_render_rows(self._h, C.byref(camera.c), W, H, row_begin, row_end,
                                         C.byref(o), ptr(out_f32, 4), ptr(out_u8, 1)))
 
+    @staticmethod
+    def _dev_ptr(buf, nbytes):
+        if buf is None:
+            return None
+        if hasattr(buf, "data_ptr"):
+            if buf.numel() * buf.element_size() < nbytes:
+                raise ValueError("device buffer too small")
+            if not buf.is_cuda or not buf.is_contiguous():
+                raise ValueError("need a contiguous device tensor")
+            return C.c_void_p(buf.data_ptr())
+        return C.c_void_p(int(buf))
+
+    def render_strips(self, camera, W, H, first_strip, strip_stride, out_f32=None, out_u8=None, *,
+                      strip_rows=8, shadows=True, face_mode=ESC_FACE_FIXED, fixed_face=0, seed=0,
+                      stage=ESC_STAGE_AUTO):
+        """Rank `first_strip` of `strip_stride`: renders strips first, first+stride, ... of
+        `strip_rows` rows (counted from h = 0) into device buffers, rows packed in ascending h.
+        Returns the number of rows rendered."""
+        rows = strip_local_rows(H, strip_rows, first_strip, strip_stride)
+        n = rows * W * 3
+        o = _options(shadows, face_mode, fixed_face, seed, stage)
+        check(self._lib.esc_render_strips(self._h, C.byref(camera.c), W, H, strip_rows,
+                                          first_strip, strip_stride, C.byref(o),
+                                          self._dev_ptr(out_f32, n * 4), self._dev_ptr(out_u8, n)))
+        return rows
+
+    def assemble_strips(self, gathered, n_ranks, rank_pitch_bytes, W, H, frame, *, strip_rows=8,
+                        bytes_per_pixel=12):
+        """gathered: n_ranks blocks of local rows (block r at r*rank_pitch_bytes) -> frame."""
+        check(self._lib.esc_assemble_strips(
+            self._h, self._dev_ptr(gathered, 0), n_ranks, rank_pitch_bytes, W, H, strip_rows,
+            bytes_per_pixel, self._dev_ptr(frame, W * H * bytes_per_pixel)))
+
     def render(self, camera, W, H, *, want_u8=False, shadows=True, face_mode=ESC_FACE_FIXED,
                fixed_face=0, seed=0, stage=ESC_STAGE_AUTO):
         """Whole frame into host numpy arrays (synchronous): fp32 (H, W, 3), h = 0 bottom row,
@@ -265,7 +298,11 @@ class Renderer:
         c = _capi.esc_counters()
         check(self._lib.esc_read_counters(self._h, C.byref(c)))
         return {"primary_rays": c.primary_rays, "hit_pixels": c.hit_pixels,
-                "shadow_rays": c.shadow_rays}
+                "shadow_rays": c.shadow_rays, "anyhit_tests": c.anyhit_tests}
+
+
+def strip_local_rows(H, strip_rows, first_strip, strip_stride):
+    return check(_capi.load().esc_strip_local_rows(H, strip_rows, first_strip, strip_stride))
 
 
 def render_multi(scene, camera, W, H, n_devices, *, want_u8=False, shadows=True,

@@ -67,7 +67,7 @@ class esc_render_options(C.Structure):
 
 class esc_counters(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("hit_pixels", C.c_uint64),
-                ("shadow_rays", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("anyhit_tests", C.c_uint64)]
 
 
 _P = C.c_void_p
@@ -112,6 +112,11 @@ SIGNATURES = {
                                   C.POINTER(ispc_light), C.c_int32, C.POINTER(ispc_triangle)]),
     "esc_render_rows": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.POINTER(esc_render_options), _P, _P]),
+    "esc_render_strips": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.POINTER(esc_render_options), _P, _P]),
+    "esc_strip_local_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "esc_assemble_strips": (C.c_int, [_P, _P, C.c_int32, C.c_size_t, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, _P]),
     "esc_reset_counters": (C.c_int, [_P]),
     "esc_read_counters": (C.c_int, [_P, C.POINTER(esc_counters)]),
     "esc_render_frame_host": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32,

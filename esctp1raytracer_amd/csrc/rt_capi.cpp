@@ -17,6 +17,9 @@
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevSphP *sph_p, hipStream_t stream);
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, hipStream_t stream);
+extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
+                                   int n_ranks, int H, int strip_rows, size_t row_bytes,
+                                   hipStream_t stream);
 
 using esc::set_error;
 
@@ -282,8 +285,8 @@ int esc_context_create(int32_t device, esc_context **out) {
     return ESC_ERR_HIP;
   }
   ctx->own_stream = true;
-  hipError_t ce = hipMalloc((void **)&ctx->d_counters, 3 * sizeof(unsigned long long));
-  if (ce == hipSuccess) ce = hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long));
+  hipError_t ce = hipMalloc((void **)&ctx->d_counters, 4 * sizeof(unsigned long long));
+  if (ce == hipSuccess) ce = hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long));
   if (ce != hipSuccess) {
     set_error(std::string("hipMalloc(counters): ") + hipGetErrorString(ce));
     esc_context_destroy(ctx);
@@ -358,31 +361,28 @@ int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle
   return commit(ctx, s);
 }
 
-int esc_render_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
-                    int32_t row_begin, int32_t row_end, const esc_render_options *opts,
-                    float *d_rgb_f32, uint8_t *d_rgb_u8) {
-  if (!ctx || !cam || !opts) {
-    set_error("esc_render_rows: bad argument");
-    return ESC_ERR_INVALID;
-  }
+} // extern "C"
+
+namespace {
+
+// the one place a frame kernel is launched from: local row lr (ascending h) maps to image row
+// h0 + (lr / strip_rows) * strip_step + lr % strip_rows
+int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H, int32_t h0,
+                      int32_t n_local_rows, int32_t strip_rows, int32_t strip_step,
+                      const esc_render_options *opts, float *d_rgb_f32, uint8_t *d_rgb_u8) {
   if (!ctx->have_scene) {
-    set_error("esc_render_rows: no scene uploaded");
-    return ESC_ERR_INVALID;
-  }
-  if (W < 2 || H < 2 || row_begin < 0 || row_end > H || row_begin > row_end) {
-    // W-1 and H-1 are divisors at main.cpp:709-710
-    set_error("esc_render_rows: need W,H >= 2 and 0 <= row_begin <= row_end <= H");
+    set_error("render: no scene uploaded");
     return ESC_ERR_INVALID;
   }
   if ((int64_t)W * H > 0x7fffffffLL) {
-    set_error("esc_render_rows: W*H exceeds the reference's int pixel index (main.cpp:784)");
+    set_error("render: W*H exceeds the reference's int pixel index (main.cpp:784)");
     return ESC_ERR_INVALID;
   }
   if (opts->face_mode == ESC_FACE_FIXED && opts->fixed_face < 0) {
-    set_error("esc_render_rows: fixed_face < 0");
+    set_error("render: fixed_face < 0");
     return ESC_ERR_INVALID;
   }
-  if (row_begin == row_end) return ESC_OK;
+  if (n_local_rows == 0) return ESC_OK;
   HIP_TRY(hipSetDevice(ctx->device));
 
   esc::RenderParams p;
@@ -393,8 +393,10 @@ int esc_render_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t 
   std::memcpy(p.vertical, cam->vertical, 12);
   p.W = W;
   p.H = H;
-  p.row_begin = row_begin;
-  p.row_end = row_end;
+  p.h0 = h0;
+  p.n_local_rows = n_local_rows;
+  p.strip_rows = strip_rows;
+  p.strip_step = strip_step;
   p.n_tri = ctx->n_tri;
   p.n_sph = ctx->n_sph;
   p.n_lights = ctx->n_lights;
@@ -434,13 +436,83 @@ int esc_render_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t 
   return ESC_OK;
 }
 
+} // namespace
+
+extern "C" {
+
+int esc_render_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
+                    int32_t row_begin, int32_t row_end, const esc_render_options *opts,
+                    float *d_rgb_f32, uint8_t *d_rgb_u8) {
+  if (!ctx || !cam || !opts) {
+    set_error("esc_render_rows: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (W < 2 || H < 2 || row_begin < 0 || row_end > H || row_begin > row_end) {
+    // W-1 and H-1 are divisors at main.cpp:709-710
+    set_error("esc_render_rows: need W,H >= 2 and 0 <= row_begin <= row_end <= H");
+    return ESC_ERR_INVALID;
+  }
+  // one "strip" taller than any image: lr / strip_rows == 0
+  return render_local_rows(ctx, cam, W, H, row_begin, row_end - row_begin, 1 << 30, 0, opts,
+                           d_rgb_f32, d_rgb_u8);
+}
+
+int esc_strip_local_rows(int32_t H, int32_t strip_rows, int32_t first_strip,
+                         int32_t strip_stride) {
+  if (H < 1 || strip_rows < 8 || strip_rows % 8 != 0 || first_strip < 0 || strip_stride < 1) {
+    set_error("esc_strip_local_rows: need H >= 1, strip_rows a positive multiple of 8, "
+              "first_strip >= 0, strip_stride >= 1");
+    return ESC_ERR_INVALID;
+  }
+  const int n_strips = (H + strip_rows - 1) / strip_rows;
+  int64_t rows = 0;
+  for (int k = first_strip; k < n_strips; k += strip_stride)
+    rows += std::min(strip_rows, H - k * strip_rows);
+  return (int)rows;
+}
+
+int esc_render_strips(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
+                      int32_t strip_rows, int32_t first_strip, int32_t strip_stride,
+                      const esc_render_options *opts, float *d_rgb_f32, uint8_t *d_rgb_u8) {
+  if (!ctx || !cam || !opts) {
+    set_error("esc_render_strips: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (W < 2 || H < 2) {
+    set_error("esc_render_strips: need W,H >= 2");
+    return ESC_ERR_INVALID;
+  }
+  const int rows = esc_strip_local_rows(H, strip_rows, first_strip, strip_stride);
+  if (rows < 0) return rows;
+  return render_local_rows(ctx, cam, W, H, first_strip * strip_rows, rows, strip_rows,
+                           strip_stride * strip_rows, opts, d_rgb_f32, d_rgb_u8);
+}
+
+int esc_assemble_strips(esc_context *ctx, const void *d_gathered, int32_t n_ranks,
+                        size_t rank_pitch_bytes, int32_t W, int32_t H, int32_t strip_rows,
+                        int32_t bytes_per_pixel, void *d_frame) {
+  if (!ctx || !d_gathered || !d_frame || n_ranks < 1 || W < 1 || H < 1 || strip_rows < 1 ||
+      bytes_per_pixel < 1) {
+    set_error("esc_assemble_strips: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  int e = esc_launch_assemble(d_gathered, d_frame, rank_pitch_bytes, n_ranks, H, strip_rows,
+                              (size_t)W * bytes_per_pixel, ctx->stream);
+  if (e) {
+    set_error(std::string("k_assemble_strips launch: ") + hipGetErrorString((hipError_t)e));
+    return ESC_ERR_HIP;
+  }
+  return ESC_OK;
+}
+
 int esc_reset_counters(esc_context *ctx) {
   if (!ctx) {
     set_error("esc_reset_counters: ctx is null");
     return ESC_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
   return ESC_OK;
 }
 
@@ -450,12 +522,13 @@ int esc_read_counters(esc_context *ctx, esc_counters *out) {
     return ESC_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  unsigned long long h[3];
+  unsigned long long h[4];
   HIP_TRY(hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   out->primary_rays = h[0];
   out->hit_pixels = h[1];
   out->shadow_rays = h[2];
+  out->anyhit_tests = h[3];
   return ESC_OK;
 }
 
@@ -502,8 +575,8 @@ int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_
     set_error("esc_render_frame_multi: bad argument");
     return ESC_ERR_INVALID;
   }
-  if (W < 2 || H < 2 || n_devices > H) {
-    set_error("esc_render_frame_multi: need W,H >= 2 and n_devices <= H");
+  if (W < 2 || H < 2) {
+    set_error("esc_render_frame_multi: need W,H >= 2");
     return ESC_ERR_INVALID;
   }
   int avail = 0;
@@ -511,12 +584,15 @@ int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_
     set_error("esc_render_frame_multi: no HIP device (no CPU fallback)");
     return ESC_ERR_NO_DEVICE;
   }
+  // 8-row strips dealt round-robin: band i renders strips i, i+n, ... (load balance, see
+  // esc_render_strips) and each strip is copied straight to its rows of the caller's frame.
+  const int kStrip = 8;
   struct Band {
     esc_context *ctx = nullptr;
     float *d_img = nullptr;
     uint8_t *d_u8 = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    int r0 = 0, r1 = 0;
+    int rows = 0;
   };
   std::vector<Band> bands((size_t)n_devices);
   int rc = ESC_OK;
@@ -540,12 +616,10 @@ int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_
       return ESC_ERR_HIP;                                                    \
     }                                                                        \
   } while (0)
-  const int rows_per = H / n_devices;
   // phase 1: one context per band; bands beyond the device count share devices round-robin
   for (int i = 0; i < n_devices && rc == ESC_OK; i++) {
     Band &b = bands[(size_t)i];
-    b.r0 = i * rows_per;
-    b.r1 = (i == n_devices - 1) ? H : (i + 1) * rows_per;
+    b.rows = esc_strip_local_rows(H, kStrip, i, n_devices);
     rc = esc_context_create(i % avail, &b.ctx);
     if (rc == ESC_OK) rc = esc_upload_scene(b.ctx, scene);
   }
@@ -554,30 +628,42 @@ int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_
     return rc;
   }
   // phase 2: launch every band before waiting on any
-  for (auto &b : bands) {
-    const size_t n = (size_t)(b.r1 - b.r0) * W * 3;
+  const int n_strips = (H + kStrip - 1) / kStrip;
+  for (int i = 0; i < n_devices; i++) {
+    Band &b = bands[(size_t)i];
+    if (b.rows == 0) continue;
+    const size_t n = (size_t)b.rows * W * 3;
     MULTI_TRY(hipSetDevice(b.ctx->device));
     if (image) MULTI_TRY(hipMalloc((void **)&b.d_img, n * sizeof(float)));
     if (rgb8) MULTI_TRY(hipMalloc((void **)&b.d_u8, n));
     MULTI_TRY(hipEventCreate(&b.t0));
     MULTI_TRY(hipEventCreate(&b.t1));
     MULTI_TRY(hipEventRecord(b.t0, b.ctx->stream));
-    rc = esc_render_rows(b.ctx, cam, W, H, b.r0, b.r1, opts, b.d_img, b.d_u8);
+    rc = esc_render_strips(b.ctx, cam, W, H, kStrip, i, n_devices, opts, b.d_img, b.d_u8);
     if (rc != ESC_OK) {
       cleanup();
       return rc;
     }
     MULTI_TRY(hipEventRecord(b.t1, b.ctx->stream));
-    // gather: each band lands at its row offset of the caller's frame
-    if (image)
-      MULTI_TRY(hipMemcpyAsync(image + (size_t)b.r0 * W * 3, b.d_img, n * sizeof(float),
-                               hipMemcpyDeviceToHost, b.ctx->stream));
-    if (rgb8)
-      MULTI_TRY(hipMemcpyAsync(rgb8 + (size_t)b.r0 * W * 3, b.d_u8, n, hipMemcpyDeviceToHost,
-                               b.ctx->stream));
+    // gather: strip k = image rows [k*8, k*8+8) sits at local rows [j*8, ...) of band i
+    size_t local_row = 0;
+    for (int k = i; k < n_strips; k += n_devices) {
+      const int h0 = k * kStrip;
+      const size_t rows = (size_t)std::min(kStrip, H - h0);
+      const size_t cnt = rows * W * 3;
+      if (image)
+        MULTI_TRY(hipMemcpyAsync(image + (size_t)h0 * W * 3, b.d_img + local_row * W * 3,
+                                 cnt * sizeof(float), hipMemcpyDeviceToHost, b.ctx->stream));
+      if (rgb8)
+        MULTI_TRY(hipMemcpyAsync(rgb8 + (size_t)h0 * W * 3, b.d_u8 + local_row * W * 3, cnt,
+                                 hipMemcpyDeviceToHost, b.ctx->stream));
+      local_row += rows;
+    }
   }
   for (size_t i = 0; i < bands.size(); i++) {
     Band &b = bands[i];
+    if (ms_per_device) ms_per_device[i] = 0.f;
+    if (b.rows == 0) continue;
     MULTI_TRY(hipSetDevice(b.ctx->device));
     MULTI_TRY(hipStreamSynchronize(b.ctx->stream));
     if (ms_per_device) MULTI_TRY(hipEventElapsedTime(&ms_per_device[i], b.t0, b.t1));

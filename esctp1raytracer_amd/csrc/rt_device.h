@@ -75,7 +75,9 @@ struct RenderParams {
   float llc[3];
   float horizontal[3];
   float vertical[3];
-  int32_t W, H, row_begin, row_end;
+  int32_t W, H;
+  // local row lr (ascending h) -> image row h0 + (lr / strip_rows) * strip_step + lr % strip_rows
+  int32_t h0, n_local_rows, strip_rows, strip_step;
   int32_t n_tri, n_sph, n_lights, n_geom;
   const DevTri *tri;
   const DevTriP *tri_p;
@@ -90,7 +92,7 @@ struct RenderParams {
   uint64_t seed;
   float *out_f32;   // band-local, may be null
   uint8_t *out_u8;  // band-local, may be null
-  unsigned long long *counters; // [3] primary, hit, shadow
+  unsigned long long *counters; // [4] primary, hit, shadow rays, any-hit tests
 };
 
 // pixel tile of one 256-thread workgroup: 4 waves as 2x2 tiles of 16x4 pixels

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "rt_device.h"
 
 namespace esc {
@@ -259,14 +261,20 @@ DEVINL void closest_sph_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
 }
 
 // ---- any-hit (main.cpp:314-329), general origin -------------------------------------------
-// tb = per-lane bound: > 0 while the lane is still looking, set to 0 once it found its FIRST
-// occluder (or if it never looked), so later primitives cannot accept (accepts need
-// eps <= t2 < tb).  tocc receives that occluder's t2 (occlusion() mutates the caller's t,
-// quirk S3).  The wave leaves a loop early once no lane is looking (checked per block of
+// Per-lane state of one occlusion() call.  tb is the bound: > 0 while the lane is still
+// looking, set to 0 once it found its FIRST occluder (or if it never looked), so later
+// primitives cannot accept (accepts need eps <= t2 < tb).  tocc receives that occluder's t2
+// (occlusion() mutates the caller's t, quirk S3) and kocc its index in (triangles, spheres)
+// order.  The wave leaves a loop early once no lane is looking (checked per block of
 // kExitStride primitives, not per primitive).
+struct Any {
+  float tb;
+  float tocc;
+  int32_t kocc;
+};
 constexpr int kExitStride = 32;
 
-DEVINL void test_tri_any(const DevTri &T, f3 o, f3 L, float &tb, float &tocc) {
+DEVINL void test_tri_any(const DevTri &T, int idx, f3 o, f3 L, Any &a) {
   const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
   const f3 pv = cross(L, e2);    // ray_triangle.h:18
   const float det = dot(e1, pv); // :21
@@ -277,17 +285,18 @@ DEVINL void test_tri_any(const DevTri &T, f3 o, f3 L, float &tb, float &tocc) {
   const bool c = tri_candidate(det, un, vn);
   if (__builtin_amdgcn_ballot_w64(c)) {
     float t2, v2;
-    if (c && tri_exact(det, un, vn, dot(e2, qv), tb, t2, v2)) {
-      tocc = t2;
-      tb = 0.f;
+    if (c && tri_exact(det, un, vn, dot(e2, qv), a.tb, t2, v2)) {
+      a.tocc = t2;
+      a.kocc = idx;
+      a.tb = 0.f;
     }
   }
 }
 
 template <typename Fetch>
-DEVINL void anyhit_tri(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
+DEVINL void anyhit_tri(Fetch rec, int n, int base, f3 o, f3 L, Any &a) {
   for (int k0 = 0; k0 < n; k0 += kExitStride) {
-    if (!__builtin_amdgcn_ballot_w64(tb > 0.f)) return; // every lane done
+    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return; // every lane done
     const int m = min(kExitStride, n - k0);
     const int m2 = m & ~1;
     if (m2) {
@@ -295,17 +304,26 @@ DEVINL void anyhit_tri(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
       for (int k = 0; k < m2; k += 2) {
         B = rec(rec.landed(A.e2[2], k0 + k + 1));
         __builtin_amdgcn_sched_barrier(0);
-        test_tri_any(A, o, L, tb, tocc);
+        test_tri_any(A, base + k0 + k, o, L, a);
         A = rec(rec.landed(B.e2[2], k0 + min(k + 2, m - 1)));
         __builtin_amdgcn_sched_barrier(0);
-        test_tri_any(B, o, L, tb, tocc);
+        test_tri_any(B, base + k0 + k + 1, o, L, a);
       }
     }
-    if (m2 < m) test_tri_any(rec(k0 + m2), o, L, tb, tocc);
+    if (m2 < m) test_tri_any(rec(k0 + m2), base + k0 + m2, o, L, a);
   }
 }
 
-DEVINL void test_sph2_any(const DevSph (&s)[2], f3 o, f3 L, float &tb, float &tocc) {
+DEVINL void accept_sph_any(float b, float q, int idx, Any &a) {
+  float t2;
+  if (sph_exact(b, q, a.tb, t2)) {
+    a.tocc = t2;
+    a.kocc = idx;
+    a.tb = 0.f;
+  }
+}
+
+DEVINL void test_sph2_any(const DevSph (&s)[2], int idx, f3 o, f3 L, Any &a) {
   float b[2], q[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -314,16 +332,15 @@ DEVINL void test_sph2_any(const DevSph (&s)[2], f3 o, f3 L, float &tb, float &to
     q[i] = b[i] * b[i] - (dot(oc, oc) - s[i].r2);
   }
   if (__builtin_amdgcn_ballot_w64(!(fmaxf(q[0], q[1]) < 0.f))) {
-    float t2;
-    if (sph_exact(b[0], q[0], tb, t2)) { tocc = t2; tb = 0.f; }
-    if (sph_exact(b[1], q[1], tb, t2)) { tocc = t2; tb = 0.f; }
+    accept_sph_any(b[0], q[0], idx, a);
+    accept_sph_any(b[1], q[1], idx + 1, a);
   }
 }
 
 template <typename Fetch>
-DEVINL void anyhit_sph(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
+DEVINL void anyhit_sph(Fetch rec, int n, int base, f3 o, f3 L, Any &a) {
   for (int k0 = 0; k0 < n; k0 += kExitStride) {
-    if (!__builtin_amdgcn_ballot_w64(tb > 0.f)) return;
+    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return;
     const int m = min(kExitStride, n - k0);
     const int m4 = m & ~3;
     if (m4) {
@@ -331,9 +348,9 @@ DEVINL void anyhit_sph(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
       fetch_batch(rec, k0, A);
       for (int k = 0; k < m4; k += 4) {
         fetch_batch(rec, rec.landed(A[1].r2, k0 + k + 2), B);
-        test_sph2_any(A, o, L, tb, tocc);
+        test_sph2_any(A, base + k0 + k, o, L, a);
         fetch_batch(rec, rec.landed(B[1].r2, k0 + min(k + 4, m - 2)), A);
-        test_sph2_any(B, o, L, tb, tocc);
+        test_sph2_any(B, base + k0 + k + 2, o, L, a);
       }
     }
     for (int k = m4; k < m; ++k) {
@@ -341,8 +358,7 @@ DEVINL void anyhit_sph(Fetch rec, int n, f3 o, f3 L, float &tb, float &tocc) {
       const f3 oc = mk(o.x - s0.cx, o.y - s0.cy, o.z - s0.cz);
       const float b0 = dot(oc, L);
       const float q0 = b0 * b0 - (dot(oc, oc) - s0.r2);
-      float t2;
-      if (sph_exact(b0, q0, tb, t2)) { tocc = t2; tb = 0.f; }
+      accept_sph_any(b0, q0, base + k0 + k, a);
     }
   }
 }
@@ -386,7 +402,7 @@ DEVINL void lds_stage(Rec *lds, const Rec *__restrict__ src, int n) {
 }
 
 // splitmix64 finaliser over (seed, pixel, light): counter-based stand-in for the
-// reference's mt19937 draw at main.cpp:743-747 (bit-identical to oracle/rt_oracle.c).
+// reference's mt19937 draw at main.cpp:743-747 (the test checker restates the same hash).
 DEVINL uint32_t face_hash(uint64_t seed, uint32_t pixel, uint32_t light, uint32_t n_faces) {
   uint64_t z = seed + (((uint64_t)pixel << 32) | (uint64_t)light) + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -406,7 +422,7 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
   // ---- workgroup -> pixel tile.  Blocks are dealt round-robin over the 8 XCDs, so block b
   // and b+8 share an L2; give each XCD one contiguous run of tiles (= contiguous framebuffer
   // rows) instead of every 8th tile.  Grid is padded to a multiple of 8; surplus blocks exit.
-  const int rows = p.row_end - p.row_begin;
+  const int rows = p.n_local_rows;
   const int tiles_x = (p.W + kTileW - 1) / kTileW;
   const int tiles_y = (rows + kTileH - 1) / kTileH;
   const int n_tiles = tiles_x * tiles_y;
@@ -420,9 +436,14 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
   const int lx = ((wave & 1) << 4) + (lane & 15);
   const int ly = ((wave >> 1) << 2) + (lane >> 4);
   const int w = tx * kTileW + lx;
-  // rows are produced top-down like main.cpp:628 (h = H-1 ... 0); tile row 0 = top of band
-  const int h = p.row_end - 1 - (ty * kTileH + ly);
-  const bool inside = (w < p.W) && (h >= p.row_begin);
+  // local row lr (ascending h) -> image row h.  A contiguous band has strip_rows >= its
+  // height, so lr / strip_rows == 0 and h = h0 + lr; cyclic strips (multi-GPU) jump by
+  // strip_step image rows per strip.  strip_rows is a multiple of kTileH (host-checked).
+  const int lr0 = ty * kTileH;
+  const int h_tile = p.h0 + (lr0 / p.strip_rows) * p.strip_step + (lr0 % p.strip_rows);
+  const int lr = lr0 + ly;
+  const int h = h_tile + ly;
+  const bool inside = (w < p.W) && (lr < rows) && (h < p.H);
 
   // ---- main.cpp:709-713 + camera.h:31-34
   const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
@@ -494,10 +515,14 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
   float t = hit.t;
   const float nl = (float)p.n_lights;
   uint32_t n_shadow = 0;
+  unsigned long long n_any = 0; // any-hit tests the reference would have executed
   for (int li = 0; li < p.n_lights; ++li) {
     const DevLight Lt = p.lights[li];
     f3 hp = N, L = N;
-    float tb = 0.f, tocc = 0.f;
+    Any a;
+    a.tb = 0.f;
+    a.tocc = 0.f;
+    a.kocc = -1;
     if (has_hit) {
       uint32_t face = (p.face_mode == 0)
                           ? (uint32_t)p.fixed_face
@@ -509,15 +534,14 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
       const float len = length(L);           // :761
       t = len - FLT_EPSILON;                 // :764
       L = normalize(L);                      // :766
-      tb = t;
+      a.tb = t;
     }
     if (p.shadows) { // :772 occlusion(): wave-uniform loops, dead lanes carry tb = 0
-      if (!(tb > 0.f)) tb = 0.f;
-      n_shadow += has_hit ? 1u : 0u;
+      if (!(a.tb > 0.f)) a.tb = 0.f;
       if (STAGE == STAGE_SMEM) {
-        if (__builtin_amdgcn_ballot_w64(tb > 0.f)) {
-          anyhit_tri(SmemFetch<DevTri>{p.tri}, p.n_tri, hp, L, tb, tocc);
-          anyhit_sph(SmemFetch<DevSph>{p.sph}, p.n_sph, hp, L, tb, tocc);
+        if (__builtin_amdgcn_ballot_w64(a.tb > 0.f)) {
+          anyhit_tri(SmemFetch<DevTri>{p.tri}, p.n_tri, 0, hp, L, a);
+          anyhit_sph(SmemFetch<DevSph>{p.sph}, p.n_sph, p.n_tri, hp, L, a);
         }
       } else {
         constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTri);
@@ -526,8 +550,7 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
           __syncthreads();
           lds_stage(reinterpret_cast<DevTri *>(lds_raw), p.tri + k0, n);
           __syncthreads();
-          anyhit_tri(LdsFetch<DevTri>{reinterpret_cast<const DevTri *>(lds_raw)}, n, hp, L, tb,
-                     tocc);
+          anyhit_tri(LdsFetch<DevTri>{reinterpret_cast<const DevTri *>(lds_raw)}, n, k0, hp, L, a);
         }
         constexpr int CS = kLdsChunkBytes / (int)sizeof(DevSph);
         for (int k0 = 0; k0 < p.n_sph; k0 += CS) {
@@ -535,16 +558,21 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
           __syncthreads();
           lds_stage(reinterpret_cast<DevSph *>(lds_raw), p.sph + k0, n);
           __syncthreads();
-          anyhit_sph(LdsFetch<DevSph>{reinterpret_cast<const DevSph *>(lds_raw)}, n, hp, L, tb,
-                     tocc);
+          anyhit_sph(LdsFetch<DevSph>{reinterpret_cast<const DevSph *>(lds_raw)}, n,
+                     p.n_tri + k0, hp, L, a);
         }
+      }
+      if (has_hit) {
+        n_shadow += 1u;
+        // tests occlusion() runs for this ray: up to and including its first occluder
+        n_any += (a.kocc >= 0) ? (unsigned)(a.kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
       }
     }
     if (has_hit) {
       f3 c = (ka * 0.5f + ke) / nl; // :769-770
-      const bool occluded = p.shadows && (tocc != 0.f);
+      const bool occluded = p.shadows && (a.kocc >= 0);
       if (occluded) {
-        t = tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
+        t = a.tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
       } else {
         const float d = dot(N, L); // :775
         if (!(d <= 0.f)) {         // :777
@@ -564,19 +592,23 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
     const uint64_t mi = __builtin_amdgcn_ballot_w64(inside);
     const uint64_t mh = __builtin_amdgcn_ballot_w64(has_hit);
     uint32_t ns = n_shadow;
-    for (int o = 32; o > 0; o >>= 1) ns += __shfl_down(ns, o);
+    unsigned long long na = n_any;
+    for (int o = 32; o > 0; o >>= 1) {
+      ns += __shfl_down(ns, o);
+      na += __shfl_down(na, o);
+    }
     if (lane == 0) {
       atomicAdd(&p.counters[0], (unsigned long long)__popcll(mi));
       atomicAdd(&p.counters[1], (unsigned long long)__popcll(mh));
       atomicAdd(&p.counters[2], (unsigned long long)ns);
+      if (na) atomicAdd(&p.counters[3], na);
     }
   }
 
   // ---- framebuffer: transpose the 32x8 tile through LDS so each store instruction writes
   // consecutive dwords of one image row (12-byte pixels would otherwise stride the lanes).
   const int w0 = tx * kTileW;
-  const int band_row0 = (p.row_end - 1 - ty * kTileH) - p.row_begin; // band-local row of ly = 0
-  const bool full_tile = (w0 + kTileW <= p.W) && (band_row0 - (kTileH - 1) >= 0);
+  const bool full_tile = (w0 + kTileW <= p.W) && (lr0 + kTileH <= rows) && (h_tile + kTileH <= p.H);
   if (p.out_f32) {
     if (full_tile) {
       const int li = (ly * kTileW + lx) * 3;
@@ -588,11 +620,11 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
       for (int i = 0; i < 3; ++i) {
         const int idx = tid + 256 * i; // 0..767
         const int row = idx / (kTileW * 3), col = idx % (kTileW * 3);
-        const size_t o = ((size_t)(band_row0 - row) * p.W + w0) * 3 + col;
+        const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + col;
         p.out_f32[o] = lds_px[idx];
       }
     } else if (inside) {
-      const size_t o = ((size_t)(h - p.row_begin) * p.W + w) * 3;
+      const size_t o = ((size_t)lr * p.W + w) * 3;
       p.out_f32[o + 0] = r;
       p.out_f32[o + 1] = g;
       p.out_f32[o + 2] = b;
@@ -612,11 +644,11 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
       __syncthreads();
       if (tid < kTileW * kTileH * 3 / 4) { // 192 dwords
         const int row = tid / (kTileW * 3 / 4), col = tid % (kTileW * 3 / 4);
-        const size_t o = ((size_t)(band_row0 - row) * p.W + w0) * 3 + (size_t)col * 4;
+        const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + (size_t)col * 4;
         *reinterpret_cast<uint32_t *>(p.out_u8 + o) = reinterpret_cast<const uint32_t *>(lb)[tid];
       }
     } else if (inside) {
-      const size_t o = ((size_t)(h - p.row_begin) * p.W + w) * 3;
+      const size_t o = ((size_t)lr * p.W + w) * 3;
       p.out_u8[o + 0] = qr;
       p.out_u8[o + 1] = qg;
       p.out_u8[o + 2] = qb;
@@ -624,7 +656,48 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// multi-GPU: rank r rendered strips r, r+N, r+2N, ... (strip k = image rows [k*S, k*S+S)).
+// After the gather, rank 0 holds N blocks of local rows; this kernel lays them out as one
+// frame.  One thread per dword (or byte) of the frame; reads and writes are both row-contiguous.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_assemble_strips(const T *__restrict__ gathered, T *__restrict__ frame, size_t rank_pitch,
+                  int n_ranks, int H, int strip_rows, int row_elems) {
+  const int h = blockIdx.y;
+  const int strip = h / strip_rows;
+  const int rank = strip % n_ranks;
+  const size_t local_row = (size_t)(strip / n_ranks) * strip_rows + (h % strip_rows);
+  const T *src = gathered + (size_t)rank * rank_pitch + local_row * row_elems;
+  T *dst = frame + (size_t)h * row_elems;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_elems; i += gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 } // namespace esc
+
+extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
+                                   int n_ranks, int H, int strip_rows, size_t row_bytes,
+                                   hipStream_t stream) {
+  if (H <= 0 || row_bytes == 0) return 0;
+  const bool dwords = (row_bytes % 4 == 0) && (rank_pitch_bytes % 4 == 0) &&
+                      (((uintptr_t)gathered | (uintptr_t)frame) % 4 == 0);
+  if (dwords) {
+    const int n = (int)(row_bytes / 4);
+    dim3 grid((unsigned)std::min((n + 255) / 256, 64), (unsigned)H);
+    hipLaunchKernelGGL(esc::k_assemble_strips<uint32_t>, grid, dim3(256), 0, stream,
+                       (const uint32_t *)gathered, (uint32_t *)frame, rank_pitch_bytes / 4, n_ranks,
+                       H, strip_rows, n);
+  } else {
+    const int n = (int)row_bytes;
+    dim3 grid((unsigned)std::min((n + 255) / 256, 64), (unsigned)H);
+    hipLaunchKernelGGL(esc::k_assemble_strips<uint8_t>, grid, dim3(256), 0, stream,
+                       (const uint8_t *)gathered, (uint8_t *)frame, rank_pitch_bytes, n_ranks, H,
+                       strip_rows, n);
+  }
+  return (int)hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------
 // host-side launchers (called from rt_capi.cpp)
@@ -640,7 +713,7 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
 }
 
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, hipStream_t stream) {
-  const int rows = p->row_end - p->row_begin;
+  const int rows = p->n_local_rows;
   if (rows <= 0 || p->W <= 0) return 0;
   const int tiles_x = (p->W + esc::kTileW - 1) / esc::kTileW;
   const int tiles_y = (rows + esc::kTileH - 1) / esc::kTileH;

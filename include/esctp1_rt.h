@@ -195,9 +195,11 @@ typedef struct {
 } esc_render_options;
 
 typedef struct {
-  uint64_t primary_rays;
-  uint64_t hit_pixels;
-  uint64_t shadow_rays;
+  uint64_t primary_rays; /* pixels rendered */
+  uint64_t hit_pixels;   /* primary rays that hit something */
+  uint64_t shadow_rays;  /* occlusion() calls (main.cpp:772): hit pixels x lights */
+  uint64_t anyhit_tests; /* primitive tests those calls execute in the reference: up to and
+                            including the first occluder, else every primitive */
 } esc_counters;
 
 /* Creates a context on HIP device `device` with its own stream.  Fails with
@@ -226,6 +228,24 @@ int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle
 int esc_render_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
                     int32_t row_begin, int32_t row_end, const esc_render_options *opts,
                     float *d_rgb_f32, uint8_t *d_rgb_u8);
+/* Multi-GPU partition: the image is cut into strips of `strip_rows` rows counted from h = 0
+ * (strip k = rows [k*strip_rows, (k+1)*strip_rows), the last one possibly short); this call
+ * renders strips first_strip, first_strip + strip_stride, ... -- i.e. rank r of N calls it
+ * with (first_strip = r, strip_stride = N).  Dealing strips round-robin balances sky rows
+ * (primary rays only) against floor rows (primary + shadow).  strip_rows must be a multiple of
+ * 8.  Output: the rendered rows packed in ascending h, esc_strip_local_rows() of them. */
+int esc_render_strips(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
+                      int32_t strip_rows, int32_t first_strip, int32_t strip_stride,
+                      const esc_render_options *opts, float *d_rgb_f32, uint8_t *d_rgb_u8);
+/* number of rows the call above renders (>= 0), or ESC_ERR_INVALID */
+int esc_strip_local_rows(int32_t H, int32_t strip_rows, int32_t first_strip,
+                         int32_t strip_stride);
+/* After a gather of N such buffers to one device (block r at d_gathered + r*rank_pitch_bytes):
+ * writes the H x W frame in (h*W+w) order.  bytes_per_pixel = 12 (fp32 RGB) or 3 (u8 RGB).
+ * Asynchronous on the context's stream. */
+int esc_assemble_strips(esc_context *ctx, const void *d_gathered, int32_t n_ranks,
+                        size_t rank_pitch_bytes, int32_t W, int32_t H, int32_t strip_rows,
+                        int32_t bytes_per_pixel, void *d_frame);
 int esc_reset_counters(esc_context *ctx);
 int esc_read_counters(esc_context *ctx, esc_counters *out);
 
@@ -233,9 +253,10 @@ int esc_read_counters(esc_context *ctx, esc_counters *out);
 int esc_render_frame_host(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H,
                           const esc_render_options *opts, float *image, uint8_t *rgb8);
 
-/* Single-process multi-GPU: rows split into n_devices contiguous bands (H/n each, the
- * remainder to the last), each rendered on its own device concurrently, bands gathered
- * into the caller's host buffers.  (bench.py uses one process per GPU + RCCL instead.) */
+/* Single-process multi-GPU: 8-row strips dealt round-robin over n_devices (band i renders
+ * strips i, i+n, ...), every band launched before any is waited on, strips copied straight
+ * into the caller's host frame.  Bands share devices when there are fewer GPUs than bands.
+ * (bench.py uses one process per GPU + an RCCL gather instead.) */
 int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_t W, int32_t H,
                            const esc_render_options *opts, int32_t n_devices, float *image,
                            uint8_t *rgb8, float *ms_per_device /* [n_devices] or NULL */);

@@ -202,18 +202,21 @@ static int closest_hit(const orc_scene *s, const float ori[3], const float dir[3
 }
 
 /* main.cpp:314-329: first accepted primitive returns; *t keeps that primitive's t2 */
-static int occlusion(const orc_scene *s, const float ori[3], const float dir[3], float *t) {
+static int occlusion(const orc_scene *s, const float ori[3], const float dir[3], float *t,
+                     uint64_t *tests) {
   float u, v;
   for (int32_t i = 0; i < s->n_geometry; i++) {
     const orc_geometry *g = &s->geometry[i];
     for (int32_t f = 0; f < g->n_faces; f++) {
       const uint32_t *face = &g->face_index[3 * f];
+      (*tests)++;
       if (orc_intersect_triangle(ori, dir, &g->vertex[3 * face[0]], &g->vertex[3 * face[1]],
                                  &g->vertex[3 * face[2]], t, &u, &v))
         return 1;
     }
   }
   for (int32_t k = 0; k < s->n_spheres; k++) {
+    (*tests)++;
     if (orc_intersect_sphere(ori, dir, &s->spheres[4 * k], t)) return 1;
   }
   return 0;
@@ -234,12 +237,12 @@ uint32_t orc_face_hash(uint64_t seed, uint32_t pixel, uint32_t light, uint32_t n
 
 /* main.cpp:698-791, triangle branch (num_triangles == 0) */
 static void scan_row(const orc_scene *s, const orc_camera *cam, int32_t W, int32_t H, int32_t h,
-                     const orc_options *o, float *image, orc_counters *cnt) {
+                     const orc_options *o, float *row_out /* W*3 */, orc_counters *cnt) {
   const float eps = FLT_EPSILON;
   const int quirk_s1 = (o->quirks & ORC_QUIRK_S1) != 0;
   const int quirk_s3 = (o->quirks & ORC_QUIRK_S3) != 0;
   for (int32_t w = 0; w < W; w++) {
-    float *px = &image[((int64_t)h * W + w) * 3];
+    float *px = &row_out[(int64_t)w * 3];
     px[0] = px[1] = px[2] = 0.f; /* vec3 default ctor zero-fills, main.cpp:557-558 */
     cnt->primary_rays++;
 
@@ -322,7 +325,7 @@ static void scan_row(const orc_scene *s, const orc_camera *cam, int32_t W, int32
 
       if (o->shadows) {
         cnt->shadow_rays++;
-        if (occlusion(s, hitp, L, &t)) continue; /* :772 */
+        if (occlusion(s, hitp, L, &t, &cnt->anyhit_tests)) continue; /* :772 */
       }
       float d = orc_dot(N, L); /* :775 */
       if (d <= 0) continue;    /* :777 */
@@ -351,7 +354,10 @@ static void scan_row(const orc_scene *s, const orc_camera *cam, int32_t W, int32
 typedef struct {
   const orc_scene *scene;
   const orc_camera *cam;
-  int32_t W, H, row_begin, row_end, tid, n_threads;
+  int32_t W, H, tid, n_threads;
+  const int32_t *rows; /* image rows to render */
+  int32_t n_rows;
+  int packed; /* 1: i-th listed row goes to image row i; 0: to image row rows[i] */
   const orc_options *opts;
   float *image;
   orc_counters cnt;
@@ -360,14 +366,17 @@ typedef struct {
 static void *worker(void *p) {
   worker_arg *a = (worker_arg *)p;
   /* rows dealt round-robin; each pixel is a pure function of (w,h) */
-  for (int32_t h = a->row_end - 1 - a->tid; h >= a->row_begin; h -= a->n_threads)
-    scan_row(a->scene, a->cam, a->W, a->H, h, a->opts, a->image, &a->cnt);
+  for (int32_t i = a->tid; i < a->n_rows; i += a->n_threads) {
+    const int32_t h = a->rows[i];
+    float *out = a->image + (int64_t)(a->packed ? i : h) * a->W * 3;
+    scan_row(a->scene, a->cam, a->W, a->H, h, a->opts, out, &a->cnt);
+  }
   return NULL;
 }
 
-void orc_render(const orc_scene *scene, const orc_camera *cam, int32_t W, int32_t H,
-                int32_t row_begin, int32_t row_end, const orc_options *opts, float *image,
-                orc_counters *counters, int32_t n_threads) {
+static void run_rows(const orc_scene *scene, const orc_camera *cam, int32_t W, int32_t H,
+                     const int32_t *rows, int32_t n_rows, int packed, const orc_options *opts,
+                     float *image, orc_counters *counters, int32_t n_threads) {
   if (n_threads < 1) n_threads = 1;
   worker_arg *args = (worker_arg *)calloc((size_t)n_threads, sizeof(worker_arg));
   pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
@@ -377,10 +386,11 @@ void orc_render(const orc_scene *scene, const orc_camera *cam, int32_t W, int32_
     a->cam = cam;
     a->W = W;
     a->H = H;
-    a->row_begin = row_begin;
-    a->row_end = row_end;
     a->tid = i;
     a->n_threads = n_threads;
+    a->rows = rows;
+    a->n_rows = n_rows;
+    a->packed = packed;
     a->opts = opts;
     a->image = image;
     if (n_threads == 1)
@@ -388,16 +398,33 @@ void orc_render(const orc_scene *scene, const orc_camera *cam, int32_t W, int32_
     else
       pthread_create(&th[i], NULL, worker, a);
   }
-  orc_counters total = {0, 0, 0};
+  orc_counters total = {0, 0, 0, 0};
   for (int32_t i = 0; i < n_threads; i++) {
     if (n_threads > 1) pthread_join(th[i], NULL);
     total.primary_rays += args[i].cnt.primary_rays;
     total.hit_pixels += args[i].cnt.hit_pixels;
     total.shadow_rays += args[i].cnt.shadow_rays;
+    total.anyhit_tests += args[i].cnt.anyhit_tests;
   }
   if (counters) *counters = total;
   free(args);
   free(th);
+}
+
+void orc_render(const orc_scene *scene, const orc_camera *cam, int32_t W, int32_t H,
+                int32_t row_begin, int32_t row_end, const orc_options *opts, float *image,
+                orc_counters *counters, int32_t n_threads) {
+  int32_t n = row_end > row_begin ? row_end - row_begin : 0;
+  int32_t *rows = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  for (int32_t i = 0; i < n; i++) rows[i] = row_end - 1 - i; /* top-down like main.cpp:628 */
+  run_rows(scene, cam, W, H, rows, n, 0, opts, image, counters, n_threads);
+  free(rows);
+}
+
+void orc_render_row_list(const orc_scene *scene, const orc_camera *cam, int32_t W, int32_t H,
+                         const int32_t *rows, int32_t n_rows, const orc_options *opts,
+                         float *packed_rows, orc_counters *counters, int32_t n_threads) {
+  run_rows(scene, cam, W, H, rows, n_rows, 1, opts, packed_rows, counters, n_threads);
 }
 
 /* ------------------------------------------------------------ PPM (S12) */

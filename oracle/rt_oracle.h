@@ -102,6 +102,7 @@ typedef struct {
   uint64_t primary_rays; /* pixels rendered */
   uint64_t hit_pixels;   /* primary rays that hit something */
   uint64_t shadow_rays;  /* occlusion() calls (0 when shadows == 0) */
+  uint64_t anyhit_tests; /* primitive tests executed inside those calls */
 } orc_counters;
 
 /* ---- pieces, exported so tests can pin them one by one ---- */
@@ -136,6 +137,12 @@ uint32_t orc_face_hash(uint64_t seed, uint32_t pixel, uint32_t light, uint32_t n
 void orc_render(const orc_scene *scene, const orc_camera *cam, int32_t W, int32_t H,
                 int32_t row_begin, int32_t row_end, const orc_options *opts, float *image,
                 orc_counters *counters, int32_t n_threads);
+
+/* Same, for an arbitrary list of image rows; row rows[i] is written to packed_rows + i*W*3.
+ * Used for bounded CPU-baseline samples and for spot checks of large frames. */
+void orc_render_row_list(const orc_scene *scene, const orc_camera *cam, int32_t W, int32_t H,
+                         const int32_t *rows, int32_t n_rows, const orc_options *opts,
+                         float *packed_rows, orc_counters *counters, int32_t n_threads);
 
 /* main.cpp:676-682: clamp >1, int(c*255); out = W*H*3 bytes in the SAME (h*W+w) order */
 void orc_quantise(const float *image, int64_t n_values, uint8_t *out);

@@ -51,7 +51,7 @@ class orc_options(C.Structure):
 
 class orc_counters(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("hit_pixels", C.c_uint64),
-                ("shadow_rays", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("anyhit_tests", C.c_uint64)]
 
 
 _oracle = None
@@ -85,6 +85,10 @@ def oracle():
         lib.orc_render.argtypes = [C.POINTER(orc_scene), C.POINTER(orc_camera), C.c_int32,
                                    C.c_int32, C.c_int32, C.c_int32, C.POINTER(orc_options), _F,
                                    C.POINTER(orc_counters), C.c_int32]
+        lib.orc_render_row_list.argtypes = [C.POINTER(orc_scene), C.POINTER(orc_camera), C.c_int32,
+                                            C.c_int32, C.POINTER(C.c_int32), C.c_int32,
+                                            C.POINTER(orc_options), _F, C.POINTER(orc_counters),
+                                            C.c_int32]
         lib.orc_quantise.argtypes = [_F, C.c_int64, C.POINTER(C.c_uint8)]
         lib.orc_write_ppm.restype = C.c_int
         lib.orc_write_ppm.argtypes = [C.c_char_p, _F, C.c_int32, C.c_int32]
@@ -258,8 +262,24 @@ def oracle_render(d, lookfrom, lookat, W, H, *, shadows=True, face_mode=ORC_FACE
                         C.byref(cnt), threads)
     if return_counters:
         return img, {"primary_rays": cnt.primary_rays, "hit_pixels": cnt.hit_pixels,
-                     "shadow_rays": cnt.shadow_rays}
+                     "shadow_rays": cnt.shadow_rays, "anyhit_tests": cnt.anyhit_tests}
     return img
+
+
+def oracle_render_rows(d, lookfrom, lookat, W, H, rows, *, shadows=True,
+                       face_mode=ORC_FACE_FIXED, fixed_face=0, seed=0, threads=1):
+    """rows: list of image rows -> (len(rows), W, 3) fp32 + counters"""
+    osc = d if isinstance(d, OracleScene) else OracleScene(d)
+    cam = oracle_camera(lookfrom, lookat, W, H)
+    o = orc_options(1 if shadows else 0, face_mode, fixed_face, seed, ORC_QUIRK_ALL)
+    rr = np.ascontiguousarray(rows, np.int32)
+    img = np.zeros((len(rr), W, 3), np.float32)
+    cnt = orc_counters()
+    oracle().orc_render_row_list(C.byref(osc.c), C.byref(cam), W, H,
+                                 rr.ctypes.data_as(C.POINTER(C.c_int32)), len(rr), C.byref(o),
+                                 fp(img), C.byref(cnt), threads)
+    return img, {"primary_rays": cnt.primary_rays, "hit_pixels": cnt.hit_pixels,
+                 "shadow_rays": cnt.shadow_rays, "anyhit_tests": cnt.anyhit_tests}
 
 
 def oracle_quantise(img):

@@ -200,6 +200,39 @@ def test_row_bands_equal_full_frame(esc, renderer):
     assert np.array_equal(u8, esc.quantise(full))
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_strips_gather_assemble(esc, renderer, world):
+    """the multi-GPU partition on one device: every rank's strips, the padded gather layout,
+    the HIP assemble kernel and its torch mirror all reproduce the 1-GPU frame"""
+    import torch
+    from esctp1raytracer_amd import multigpu
+    sc, d = synthetic_dict(esc, "c3", 200)
+    eye, look = esc.synthetic_view()
+    W, H = 136, 77  # ragged: last strip is 5 rows, W % 32 != 0
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    full, full_u8 = renderer.render(cam, W, H, want_u8=True)
+    max_rows = multigpu.max_local_rows(H, world)
+    for dtype, px, ref in ((torch.float32, 12, full), (torch.uint8, 3, full_u8)):
+        gathered = torch.zeros(world, max_rows * W * 3, dtype=dtype, device="cuda:0")
+        for rank in range(world):
+            rows = multigpu.local_rows(H, rank, world)
+            assert rows == esc.strip_local_rows(H, 8, rank, world)
+            kw = {"out_f32": gathered[rank]} if dtype == torch.float32 else {"out_u8": gathered[rank]}
+            assert renderer.render_strips(cam, W, H, rank, world, **kw) == rows
+        renderer.synchronize()
+        frame = torch.zeros(H * W * 3, dtype=dtype, device="cuda:0")
+        renderer.assemble_strips(gathered, world, max_rows * W * px, W, H, frame, bytes_per_pixel=px)
+        renderer.synchronize()
+        got = frame.cpu().numpy().reshape(H, W, 3)
+        mirror = multigpu.assemble_frame_torch(gathered, world, W, H).cpu().numpy()
+        assert np.array_equal(got, mirror)
+        if dtype == torch.float32:
+            assert_bit_equal(got, ref, f"strips world={world}")
+        else:
+            assert np.array_equal(got, ref)
+
+
 def test_trace_drop_in(esc, renderer):
     """The ispc::trace symbol on FlatScene arrays == the scene path, with and without the
     reference's centroid-x sort (the sort only permutes equal-t ties)."""

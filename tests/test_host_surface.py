@@ -1,0 +1,238 @@
+"""CPU-side tests of the drop-in boundary: the C ABI loads and exports every declared symbol,
+the host half (scene model, loader, camera, flatten, PPM) behaves like the reference's, and
+the product refuses to render without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = ol.ROOT
+
+
+@pytest.fixture(scope="module")
+def esc():
+    import esctp1raytracer_amd as m
+    return m
+
+
+def test_library_exports_every_declared_symbol(esc):
+    from esctp1raytracer_amd import _capi
+    header = open(os.path.join(ROOT, "include", "esctp1_rt.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(esc_[a-z0-9_]+|trace)\s*\(", header))
+    declared -= {"esc_scene", "esc_context", "esc_flat_scene"}
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = _capi.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    nm = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True,
+                        text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln}
+    assert declared <= exported
+
+
+def test_struct_layouts_match_ispc_headers():
+    """ispc_helpers.h:16-29,52-65: 140-byte triangle, 24-byte light (LP64), 44-byte camera"""
+    from esctp1raytracer_amd import _capi
+    assert C.sizeof(_capi.ispc_triangle) == 140
+    assert C.sizeof(_capi.ispc_light) == 24
+    assert C.sizeof(_capi.ispc_cam) == 44
+    assert _capi.ispc_triangle.ka.offset == 88 and _capi.ispc_triangle.Ns.offset == 136
+
+
+def test_library_contains_gfx950_code_object():
+    from esctp1raytracer_amd import _capi
+    blob = open(_capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_render" in blob
+
+
+def test_no_gpu_means_error_not_fallback(esc):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(esc.EscError) as e:
+        esc.Renderer(0)
+    assert e.value.code == -6  # ESC_ERR_NO_DEVICE
+    sc = esc.Scene.synthetic("c2")
+    cam = esc.Camera.for_image(*esc.synthetic_view(), 64, 48)
+    with pytest.raises(esc.EscError):
+        esc.render_multi(sc, cam, 64, 48, 2)
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    from esctp1raytracer_amd import _capi
+    ldd = subprocess.run(["ldd", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd and "ref_pieces" not in ldd
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "esctp1raytracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"#\s*include[^\n]*rt_oracle|import\s+oracle_lib|"
+                                     r"from\s+oracle_lib|liboracle|libref_pieces|orc_[a-z_]+\(",
+                                     txt), f
+
+
+# ------------------------------------------------------------------ loader (sceneloader.cpp)
+LOADER_DUMPS = ["one", "two", "CornellBox-Original", "CornellBox-Mirror", "CornellBox-Sphere",
+                "CornellBox-Water", "CornellBox-Empty-CO", "CornellBox-Empty-RG",
+                "CornellBox-Empty-White", "CornellBox-Empty-Squashed", "cornell_box", "water"]
+
+
+def _assert_same_scene(mine, refd):
+    assert len(mine["geometry"]) == len(refd["geometry"])
+    assert mine["light_sources"] == refd["light_sources"]
+    for a, b in zip(mine["geometry"], refd["geometry"]):
+        for k in ("vertex", "normals", "face_index", "material"):
+            assert a[k].shape == b[k].shape, k
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("name", ["one", "two"])
+def test_loader_on_committed_obj_fixtures(esc, name, golden_dir):
+    sc = esc.Scene.load_obj(os.path.join(golden_dir, "scenes", name + ".obj"))
+    _assert_same_scene(ol.scene_from_product(sc), ol.load_dump(name))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/models"),
+                    reason="bundled models live in the reference tree only")
+@pytest.mark.parametrize("name", LOADER_DUMPS[2:])
+def test_loader_bit_equal_to_reference_loader_dump(esc, name):
+    """every bundled OBJ the reference can load: geometry split (quirk S11), de-indexing,
+    tinyobj's digit-by-digit float parse, normalised normals, light list"""
+    sub = "" if name in ("cornell_box",) else "cornell/"
+    sc = esc.Scene.load_obj(f"/root/reference/src/models/{sub}{name}.obj")
+    _assert_same_scene(ol.scene_from_product(sc), ol.load_dump(name))
+    if name == "CornellBox-Original":  # S11: short box joins leftWall
+        assert [len(g["face_index"]) for g in ol.load_dump(name)["geometry"]] == [2, 2, 2, 2, 14, 12, 2]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/models"), reason="needs bundled models")
+def test_loader_rejects_what_the_reference_rejects(esc, golden_dir):
+    throws = [str(n) for n in np.load(golden_dir + "/loader_throws.npz")["names"]]
+    assert sorted(throws) == ["CornellBox-Glossy", "CornellBox-Glossy-Floor"]  # quirk S10
+    for n in throws:
+        with pytest.raises(esc.EscError) as e:
+            esc.Scene.load_obj(f"/root/reference/src/models/cornell/{n}.obj")
+        assert e.value.code == -4
+
+
+def test_loader_errors(esc, tmp_path):
+    with pytest.raises(esc.EscError) as e:
+        esc.Scene.load_obj(tmp_path / "nope.obj")
+    assert e.value.code == -3
+    p = tmp_path / "nomtl.obj"
+    p.write_text("mtllib missing.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl x\nf 1 2 3\n")
+    with pytest.raises(esc.EscError) as e:  # "WARN: Material file not found" is fatal (S10)
+        esc.Scene.load_obj(p)
+    assert e.value.code == -4
+
+
+def test_loader_number_parser_and_polygons(esc, tmp_path):
+    """negative indices, a quad (fan triangulation), exponents, v/t/n corners"""
+    (tmp_path / "m.mtl").write_text("newmtl a\nKa 0.1 0.2 0.3\nKd 1e-1 2.5E+0 .5\nKe 0 0 0\nNs 3\n")
+    (tmp_path / "q.obj").write_text(
+        "mtllib m.mtl\nv 0 0 0\nv 1.5 0 0\nv 1.5 2.25 0\nv 0 2.25 1e-3\nvt 0 0\nvn 0 0 2\n"
+        "g quad\nusemtl a\nf -4/1/1 -3/1/1 -2/1/1 -1/1/1\n")
+    d = ol.scene_from_product(esc.Scene.load_obj(tmp_path / "q.obj"))
+    g = d["geometry"][0]
+    assert g["face_index"].tolist() == [[0, 1, 2], [3, 4, 5]]
+    assert g["vertex"].tolist() == [[0, 0, 0], [1.5, 0, 0], [1.5, 2.25, 0],
+                                    [0, 0, 0], [1.5, 2.25, 0], [0, 2.25, np.float32(1e-3)]]
+    assert np.allclose(g["normals"], [[0, 0, 1]] * 6)
+    assert g["material"].tolist()[:6] == [np.float32(0.1), np.float32(0.2), np.float32(0.3),
+                                          np.float32(0.1), 2.5, 0.0]  # ".5" has no leading digit
+    assert g["material"][12] == 3.0
+
+
+# ------------------------------------------------------------------ scene model / camera
+def test_scene_build_introspect_roundtrip(esc):
+    d = ol.scene_two()
+    sc = ol.scene_to_product(d)
+    _assert_same_scene(ol.scene_from_product(sc), d)
+    assert sc.info() == {"n_geometry": 4, "n_lights": 2, "n_triangles": 6, "n_spheres": 0}
+    with pytest.raises(esc.EscError):
+        sc.add_geometry([[0, 0, 0]] * 3, [[0, 1, 3]], ol.WHITE)  # face index out of range
+
+
+def test_camera_matches_reference_outputs(esc, golden_dir):
+    with np.load(golden_dir + "/ref_pieces.npz") as f:
+        z = {k: f[k] for k in f.files}
+    for i in range(len(z["cam_vfov"])):
+        cam = esc.Camera(z["cam_eye"][i], z["cam_look"][i], (0, 1, 0), z["cam_vfov"][i],
+                         z["cam_aspect"][i])
+        v = cam.vectors()
+        got = np.concatenate([v["origin"], v["lower_left_corner"], v["horizontal"], v["vertical"]])
+        assert np.array_equal(got.view(np.uint32), z["cam_vectors"][i].view(np.uint32)), i
+
+
+def test_synthetic_scenes_are_frozen(esc):
+    """BASELINE configs: counts and a few exact values, so the workload cannot drift"""
+    for cfg, n in (("c2", 100), ("c3", 1000), ("c4", 10000)):
+        sc = esc.Scene.synthetic(cfg)
+        assert sc.info() == {"n_geometry": 2, "n_lights": 1, "n_triangles": 3, "n_spheres": n}
+    s, m = esc.Scene.synthetic("c4").spheres()
+    assert np.allclose(s[0], [-7.932042, 2.0471272, -14.4721775, 0.11074812], rtol=0, atol=1e-6)
+    assert s[:, 3].min() >= 0.05 and s[:, 3].max() <= 0.2 and (m[:, 6:12] == 0).all()
+    c5 = esc.Scene.synthetic("c5")
+    assert c5.info() == {"n_geometry": 2, "n_lights": 1, "n_triangles": 100353, "n_spheres": 0}
+    eye, look = esc.synthetic_view()
+    assert eye.tolist() == [0, 3, 6] and look.tolist() == [0, 2, -8]
+
+
+# ------------------------------------------------------------------ flatten (flatten_iscp.cpp)
+def test_flatten_ispc(esc):
+    sc = ol.scene_to_product(ol.load_dump("CornellBox-Original"))
+    flat = sc.flatten_ispc(False)
+    assert (flat.num_triangles, flat.num_lights, flat.num_light_triangles) == (36, 1, 2)
+    d = ol.load_dump("CornellBox-Original")
+    k = 0
+    for gi, g in enumerate(d["geometry"]):
+        for f, face in enumerate(g["face_index"]):
+            t = flat.triangles[k]
+            assert (t.geom_id, t.prim_id, t.has_normals, t.is_light) == (gi, f, 0, int(gi == 6))
+            assert np.array_equal(np.array(t.vertices, np.float32), g["vertex"][face])
+            assert np.array(t.kd, np.float32).tolist() == g["material"][3:6].tolist()
+            k += 1
+    L = flat.lights[0]
+    assert L.geom_id == 6 and [L.light_faces[i] for i in range(L.num_light_faces)] == [0, 1]
+    srt = sc.flatten_ispc(True)  # flatten_iscp.cpp:110: ascending centroid x
+    cx = [sum(srt.triangles[i].vertices[v][0] for v in range(3)) for i in range(36)]
+    assert all(np.float32(a / 3) <= np.float32(b / 3) for a, b in zip(cx, cx[1:]))
+    with pytest.raises(esc.EscError):
+        esc.Scene.synthetic("c2").flatten_ispc()  # spheres have no ispc_triangle form
+
+
+# ------------------------------------------------------------------ PPM (main.cpp:658-689)
+def test_ppm_writer_equals_reference_format(esc, tmp_path):
+    rng = np.random.default_rng(3)
+    img = rng.uniform(-0.2, 1.4, (37, 53, 3)).astype(np.float32)
+    img[0, 0] = (1.0, 0.999999, 0.0)
+    a, b = tmp_path / "a.ppm", tmp_path / "b.ppm"
+    esc.write_ppm(a, np.maximum(img, 0))
+    assert ol.oracle().orc_write_ppm(str(b).encode(), ol.fp(np.maximum(img, 0)), 53, 37) == 0
+    assert a.read_bytes() == b.read_bytes()
+    lines = a.read_text().split("\n")
+    assert lines[:3] == ["P3", "53 37", "255"] and len(lines) == 3 + 37 * 53 + 1
+    q = esc.quantise(np.maximum(img, 0))
+    assert np.array_equal(q, ol.oracle_quantise(np.maximum(img, 0)))
+    assert q[0, 0].tolist() == [255, 254, 0]  # clamp only > 1, truncation not rounding
+    # first text row is the TOP row h = H-1
+    assert lines[3] == " ".join(str(v) for v in q[36, 0])
+    esc.write_ppm(tmp_path / "c.ppm", q)
+    assert (tmp_path / "c.ppm").read_bytes() == a.read_bytes()
+
+
+def test_viewer_cli_surface():
+    """flags of main.cpp:430-535 are accepted; an unknown flag is rejected like :531-534"""
+    exe = os.path.join(ROOT, "bin", "ESCViewer2021")
+    if not os.path.exists(exe):
+        pytest.skip("viewer not built")
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Invalid Argument: --bogus" in r.stderr
+    r = subprocess.run([exe, "-v", "1,2"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Error parsing view" in r.stderr
