@@ -62,7 +62,8 @@ class ispc_cam(C.Structure):  # ispc_helpers.h:59-65
 
 class esc_render_options(C.Structure):
     _fields_ = [("shadows", C.c_int32), ("face_mode", C.c_int32), ("fixed_face", C.c_int32),
-                ("stage", C.c_int32), ("seed", C.c_uint64)]
+                ("stage", C.c_int32), ("seed", C.c_uint64), ("pixels_per_lane", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class esc_counters(C.Structure):

@@ -16,7 +16,8 @@
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevSphP *sph_p, hipStream_t stream);
-extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, hipStream_t stream);
+extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px,
+                                 hipStream_t stream);
 extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
                                    int n_ranks, int H, int strip_rows, size_t row_bytes,
                                    hipStream_t stream);
@@ -382,6 +383,11 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     set_error("render: fixed_face < 0");
     return ESC_ERR_INVALID;
   }
+  if (opts->pixels_per_lane != 0 && opts->pixels_per_lane != 1 && opts->pixels_per_lane != 2 &&
+      opts->pixels_per_lane != 4) {
+    set_error("render: pixels_per_lane must be 0 (auto), 1, 2 or 4");
+    return ESC_ERR_INVALID;
+  }
   if (n_local_rows == 0) return ESC_OK;
   HIP_TRY(hipSetDevice(ctx->device));
 
@@ -428,7 +434,10 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     ctx->prepared = true;
   }
   const int stage = (opts->stage == ESC_STAGE_LDS) ? 2 : 1; // AUTO -> SMEM (measured)
-  int e = esc_launch_render(&p, stage, ctx->stream);
+  // AUTO: measured on the c4 workload: 1 pixel per lane when shadow rays
+  // are traced, 2 (packed fp32) for primary-only frames
+  const int px = opts->pixels_per_lane ? opts->pixels_per_lane : (opts->shadows ? 1 : 2);
+  int e = esc_launch_render(&p, stage, px, ctx->stream);
   if (e) {
     set_error(std::string("k_render launch: ") + hipGetErrorString((hipError_t)e));
     return ESC_ERR_HIP;

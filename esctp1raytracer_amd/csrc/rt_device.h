@@ -95,8 +95,8 @@ struct RenderParams {
   unsigned long long *counters; // [4] primary, hit, shadow rays, any-hit tests
 };
 
-// pixel tile of one 256-thread workgroup: 4 waves as 2x2 tiles of 16x4 pixels
-constexpr int kTileW = 32;
+// pixel tile of one 256-thread workgroup: 2 x 2 waves, each wave (16*PX) x 4 pixels, so the
+// tile is (32*PX) x 8 with PX = pixels per lane
 constexpr int kTileH = 8;
 constexpr int kLdsChunkBytes = 32768; // LDS staging chunk (ESC_STAGE_LDS)
 

@@ -57,6 +57,51 @@ DEVINL f3 normalize(f3 v) { return v / sqrtf(dot(v, v)); } // vec.h:135
 DEVINL float length(f3 v) { return sqrtf(dot(v, v)); }     // vec.h:139
 
 // ---------------------------------------------------------------------------------------
+// lane vectors.  A work-item carries PX pixels; the hot loops see them as NV values of type V,
+// where V = float (1 pixel) or v2f (2 pixels in an even/odd VGPR pair).  Arithmetic on v2f
+// compiles to v_pk_mul_f32 / v_pk_add_f32: each half is rounded exactly like the scalar
+// instruction (no fusion), so results are bit-identical, while the pair issues in ~1.5x the
+// time of one scalar op (tools/ubench/valu_rate.hip: 59 -> 77 Tlane-op/s on MI355X).
+// ---------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <typename V> struct lanes_of { static constexpr int n = 1; };
+template <> struct lanes_of<v2f> { static constexpr int n = 2; };
+DEVINL float comp(float v, int) { return v; }
+DEVINL float comp(v2f v, int c) { return c ? v.y : v.x; }
+DEVINL void set_comp(float &v, int, float x) { v = x; }
+DEVINL void set_comp(v2f &v, int c, float x) {
+  if (c) v.y = x; else v.x = x;
+}
+
+template <typename V> struct V3 {
+  V x, y, z;
+};
+template <typename V> DEVINL V3<V> operator-(V3<V> a, V3<V> b) {
+  return V3<V>{a.x - b.x, a.y - b.y, a.z - b.z};
+}
+template <typename V> DEVINL V dotv(V3<V> a, V3<V> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// uniform (per-primitive) operands broadcast to every pixel
+template <typename V> DEVINL V dotu(f3 a, V3<V> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+template <typename V> DEVINL V3<V> sub_u(V3<V> a, f3 b) { return V3<V>{a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename V> DEVINL V3<V> cross_vu(V3<V> a, f3 b) { // cross(a, b), vec.h:103 order
+  return V3<V>{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// gather PX per-pixel f3 into NV lane vectors
+template <typename V, int NV>
+DEVINL void pack3(const f3 *src, V3<V> (&dst)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int c = 0; c < lanes_of<V>::n; ++c) {
+      const f3 v = src[j * lanes_of<V>::n + c];
+      set_comp(dst[j].x, c, v.x);
+      set_comp(dst[j].y, c, v.y);
+      set_comp(dst[j].z, c, v.z);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // exact tails (rare paths)
 // ---------------------------------------------------------------------------------------
 
@@ -140,6 +185,12 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, i
 
 // ---------------------------------------------------------------------------------------
 // primitive loops.  `rec(k)` yields record k wave-uniformly (SGPRs or LDS broadcast).
+//
+// Every lane carries PX pixels (same row, 16 columns apart).  A wave therefore amortises each
+// primitive fetch, each wave-uniform branch and each s_waitcnt over PX x 64 rays instead of
+// 64: at PX = 1 the rocprofv3 counters showed the VALU pipe 66 % busy with a quarter of all
+// wave-cycles parked on scalar-load waits (profiles/r01_c4_1gpu); the arithmetic per ray is
+// unchanged.
 // ---------------------------------------------------------------------------------------
 
 struct Hit {
@@ -162,110 +213,126 @@ DEVINL void fetch_batch(Fetch rec, int k, Rec (&r)[B]) {
 }
 
 // ---- closest hit, primary rays, triangles ------------------------------------------------
-DEVINL void tri_primary_numerators(const DevTriP &T, f3 d, float &det, float &un, float &vn) {
-  const f3 pv = cross(d, ld3(T.e2)); // ray_triangle.h:18
-  det = dot(ld3(T.e1), pv);          // :21
-  un = dot(ld3(T.tv), pv);           // :32 numerator
-  vn = dot(d, ld3(T.qv));            // :40 numerator
-}
-
-DEVINL void test_tri2_primary(const DevTriP (&T)[2], int idx, f3 d, Hit &h) {
-  float da, ua, va, db, ub, vb;
-  tri_primary_numerators(T[0], d, da, ua, va);
-  tri_primary_numerators(T[1], d, db, ub, vb);
-  const bool ca = tri_candidate(da, ua, va), cb = tri_candidate(db, ub, vb);
-  if (__builtin_amdgcn_ballot_w64(ca | cb)) { // wave-uniform skip of the f64 tail
-    float t2, v2;
-    if (ca && tri_exact(da, ua, va, T[0].tnum, h.t, t2, v2)) {
-      h.t = t2;
-      h.v = v2;
-      h.idx = idx;
+template <typename V, int NV>
+DEVINL void test_tri2_primary(const DevTriP (&T)[2], int idx, const V3<V> (&d)[NV],
+                              Hit (&h)[NV * lanes_of<V>::n]) {
+  constexpr int LN = lanes_of<V>::n;
+  V det[NV][2], un[NV][2], vn[NV][2];
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const V3<V> pv = cross_vu(d[j], ld3(T[i].e2)); // ray_triangle.h:18
+      det[j][i] = dotu(ld3(T[i].e1), pv);            // :21
+      un[j][i] = dotu(ld3(T[i].tv), pv);             // :32 numerator
+      vn[j][i] = dotu(ld3(T[i].qv), d[j]);           // :40 numerator (dot is commutative per term)
+#pragma unroll
+      for (int c = 0; c < LN; ++c)
+        any |= tri_candidate(comp(det[j][i], c), comp(un[j][i], c), comp(vn[j][i], c));
     }
-    if (cb && tri_exact(db, ub, vb, T[1].tnum, h.t, t2, v2)) {
-      h.t = t2;
-      h.v = v2;
-      h.idx = idx + 1;
-    }
+  if (__builtin_amdgcn_ballot_w64(any)) { // wave-uniform skip of the f64 tail
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int c = 0; c < LN; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          Hit &hh = h[j * LN + c];
+          const float de = comp(det[j][i], c), u = comp(un[j][i], c), v = comp(vn[j][i], c);
+          float t2, v2;
+          if (tri_candidate(de, u, v) && tri_exact(de, u, v, T[i].tnum, hh.t, t2, v2)) {
+            hh.t = t2;
+            hh.v = v2;
+            hh.idx = idx + i;
+          }
+        }
   }
 }
 
-template <typename Fetch>
-DEVINL void closest_tri_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
+template <typename V, int NV, typename Fetch>
+DEVINL void closest_tri_primary(Fetch rec, int n, int base, const V3<V> (&d)[NV],
+                                Hit (&h)[NV * lanes_of<V>::n]) {
   const int n4 = n & ~3;
   if (n4) {
     DevTriP A[2], B[2];
     fetch_batch(rec, 0, A);
     for (int k = 0; k < n4; k += 4) {
       fetch_batch(rec, rec.landed(A[1].tnum, k + 2), B);
-      test_tri2_primary(A, base + k, d, h);
+      test_tri2_primary<V, NV>(A, base + k, d, h);
       fetch_batch(rec, rec.landed(B[1].tnum, min(k + 4, n - 2)), A); // clamped: last one unused
-      test_tri2_primary(B, base + k + 2, d, h);
+      test_tri2_primary<V, NV>(B, base + k + 2, d, h);
     }
   }
-  for (int k = n4; k < n; ++k) {
-    const DevTriP T = rec(k);
-    float da, ua, va, t2, v2;
-    tri_primary_numerators(T, d, da, ua, va);
-    if (tri_candidate(da, ua, va) && tri_exact(da, ua, va, T.tnum, h.t, t2, v2)) {
-      h.t = t2;
-      h.v = v2;
-      h.idx = base + k;
-    }
+  for (int k = n4; k + 1 <= n; k += 1) {
+    // remainder: reuse the pair body with the last record duplicated as a dead second slot
+    DevTriP P[2] = {rec(k), rec(k)};
+    P[1].e1[0] = P[1].e1[1] = P[1].e1[2] = 0.f; // det = 0 -> |det| < eps -> rejected
+    P[1].tv[0] = P[1].tv[1] = P[1].tv[2] = 0.f;
+    P[1].qv[0] = P[1].qv[1] = P[1].qv[2] = 0.f;
+    test_tri2_primary<V, NV>(P, base + k, d, h);
   }
 }
 
 // ---- closest hit, primary rays, spheres ---------------------------------------------------
-DEVINL void test_sph4_primary(const DevSphP (&s)[4], int idx, f3 d, Hit &h) {
-  float b[4], q[4];
+template <typename V, int NV, int NB>
+DEVINL void test_sph_primary(const DevSphP (&s)[NB], int idx, const V3<V> (&d)[NV],
+                             Hit (&h)[NV * lanes_of<V>::n]) {
+  constexpr int LN = lanes_of<V>::n;
+  V b[NV][NB], q[NV][NB];
+  float m = -1.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    b[i] = (s[i].ocx * d.x + s[i].ocy * d.y) + s[i].ocz * d.z;
-    q[i] = b[i] * b[i] - s[i].cc;
-  }
-  const float m = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      b[j][i] = (s[i].ocx * d[j].x + s[i].ocy * d[j].y) + s[i].ocz * d[j].z;
+      q[j][i] = b[j][i] * b[j][i] - s[i].cc;
+#pragma unroll
+      for (int c = 0; c < LN; ++c) m = fmaxf(m, comp(q[j][i], c));
+    }
   if (__builtin_amdgcn_ballot_w64(!(m < 0.f))) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float t2;
-      if (sph_exact(b[i], q[i], h.t, t2)) {
-        h.t = t2;
-        h.idx = idx + i;
-      }
-    }
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int c = 0; c < LN; ++c)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          Hit &hh = h[j * LN + c];
+          float t2;
+          if (sph_exact(comp(b[j][i], c), comp(q[j][i], c), hh.t, t2)) {
+            hh.t = t2;
+            hh.idx = idx + i;
+          }
+        }
   }
 }
 
-template <typename Fetch>
-DEVINL void closest_sph_primary(Fetch rec, int n, int base, f3 d, Hit &h) {
+template <typename V, int NV, typename Fetch>
+DEVINL void closest_sph_primary(Fetch rec, int n, int base, const V3<V> (&d)[NV],
+                                Hit (&h)[NV * lanes_of<V>::n]) {
   const int n8 = n & ~7;
   if (n8) {
     DevSphP A[4], B[4];
     fetch_batch(rec, 0, A);
     for (int k = 0; k < n8; k += 8) {
       fetch_batch(rec, rec.landed(A[3].cc, k + 4), B);
-      test_sph4_primary(A, base + k, d, h);
+      test_sph_primary<V, NV, 4>(A, base + k, d, h);
       fetch_batch(rec, rec.landed(B[3].cc, min(k + 8, n - 4)), A);
-      test_sph4_primary(B, base + k + 4, d, h);
+      test_sph_primary<V, NV, 4>(B, base + k + 4, d, h);
     }
   }
   for (int k = n8; k < n; ++k) {
-    const DevSphP s0 = rec(k);
-    const float b0 = (s0.ocx * d.x + s0.ocy * d.y) + s0.ocz * d.z;
-    const float q0 = b0 * b0 - s0.cc;
-    float t2;
-    if (sph_exact(b0, q0, h.t, t2)) {
-      h.t = t2;
-      h.idx = base + k;
-    }
+    const DevSphP s0[1] = {rec(k)};
+    test_sph_primary<V, NV, 1>(s0, base + k, d, h);
   }
 }
 
 // ---- any-hit (main.cpp:314-329), general origin -------------------------------------------
-// Per-lane state of one occlusion() call.  tb is the bound: > 0 while the lane is still
+// Per-pixel state of one occlusion() call.  tb is the bound: > 0 while the ray is still
 // looking, set to 0 once it found its FIRST occluder (or if it never looked), so later
 // primitives cannot accept (accepts need eps <= t2 < tb).  tocc receives that occluder's t2
 // (occlusion() mutates the caller's t, quirk S3) and kocc its index in (triangles, spheres)
-// order.  The wave leaves a loop early once no lane is looking (checked per block of
+// order.  The wave leaves a loop early once no ray is looking (checked per block of
 // kExitStride primitives, not per primitive).
 struct Any {
   float tb;
@@ -274,29 +341,57 @@ struct Any {
 };
 constexpr int kExitStride = 32;
 
-DEVINL void test_tri_any(const DevTri &T, int idx, f3 o, f3 L, Any &a) {
-  const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
-  const f3 pv = cross(L, e2);    // ray_triangle.h:18
-  const float det = dot(e1, pv); // :21
-  const f3 tv = o - ld3(T.v0);   // :29
-  const float un = dot(tv, pv);  // :32
-  const f3 qv = cross(tv, e1);   // :37
-  const float vn = dot(L, qv);   // :40
-  const bool c = tri_candidate(det, un, vn);
-  if (__builtin_amdgcn_ballot_w64(c)) {
-    float t2, v2;
-    if (c && tri_exact(det, un, vn, dot(e2, qv), a.tb, t2, v2)) {
-      a.tocc = t2;
-      a.kocc = idx;
-      a.tb = 0.f;
+template <int PX> DEVINL bool any_looking(const Any (&a)[PX]) {
+  bool l = false;
+#pragma unroll
+  for (int p = 0; p < PX; ++p) l |= a[p].tb > 0.f;
+  return __builtin_amdgcn_ballot_w64(l) != 0;
+}
+
+template <typename V, int NV>
+DEVINL void test_tri_any(const DevTri &T, int idx, const V3<V> (&o)[NV], const V3<V> (&L)[NV],
+                         Any (&a)[NV * lanes_of<V>::n]) {
+  constexpr int LN = lanes_of<V>::n;
+  const f3 e1 = ld3(T.e1), e2 = ld3(T.e2), v0 = ld3(T.v0);
+  V det[NV], un[NV], vn[NV];
+  V3<V> qv[NV];
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const V3<V> pv = cross_vu(L[j], e2); // ray_triangle.h:18
+    det[j] = dotu(e1, pv);               // :21
+    const V3<V> tv = sub_u(o[j], v0);    // :29
+    un[j] = dotv(tv, pv);                // :32
+    qv[j] = cross_vu(tv, e1);            // :37
+    vn[j] = dotv(L[j], qv[j]);           // :40
+#pragma unroll
+    for (int c = 0; c < LN; ++c)
+      any |= tri_candidate(comp(det[j], c), comp(un[j], c), comp(vn[j], c));
+  }
+  if (__builtin_amdgcn_ballot_w64(any)) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const V tn = dotu(e2, qv[j]); // :45 numerator
+#pragma unroll
+      for (int c = 0; c < LN; ++c) {
+        Any &aa = a[j * LN + c];
+        const float de = comp(det[j], c), u = comp(un[j], c), v = comp(vn[j], c);
+        float t2, v2;
+        if (tri_candidate(de, u, v) && tri_exact(de, u, v, comp(tn, c), aa.tb, t2, v2)) {
+          aa.tocc = t2;
+          aa.kocc = idx;
+          aa.tb = 0.f;
+        }
+      }
     }
   }
 }
 
-template <typename Fetch>
-DEVINL void anyhit_tri(Fetch rec, int n, int base, f3 o, f3 L, Any &a) {
+template <typename V, int NV, typename Fetch>
+DEVINL void anyhit_tri(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V3<V> (&L)[NV],
+                       Any (&a)[NV * lanes_of<V>::n]) {
   for (int k0 = 0; k0 < n; k0 += kExitStride) {
-    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return; // every lane done
+    if (!any_looking(a)) return; // every ray done
     const int m = min(kExitStride, n - k0);
     const int m2 = m & ~1;
     if (m2) {
@@ -304,43 +399,55 @@ DEVINL void anyhit_tri(Fetch rec, int n, int base, f3 o, f3 L, Any &a) {
       for (int k = 0; k < m2; k += 2) {
         B = rec(rec.landed(A.e2[2], k0 + k + 1));
         __builtin_amdgcn_sched_barrier(0);
-        test_tri_any(A, base + k0 + k, o, L, a);
+        test_tri_any<V, NV>(A, base + k0 + k, o, L, a);
         A = rec(rec.landed(B.e2[2], k0 + min(k + 2, m - 1)));
         __builtin_amdgcn_sched_barrier(0);
-        test_tri_any(B, base + k0 + k + 1, o, L, a);
+        test_tri_any<V, NV>(B, base + k0 + k + 1, o, L, a);
       }
     }
-    if (m2 < m) test_tri_any(rec(k0 + m2), base + k0 + m2, o, L, a);
+    if (m2 < m) test_tri_any<V, NV>(rec(k0 + m2), base + k0 + m2, o, L, a);
   }
 }
 
-DEVINL void accept_sph_any(float b, float q, int idx, Any &a) {
-  float t2;
-  if (sph_exact(b, q, a.tb, t2)) {
-    a.tocc = t2;
-    a.kocc = idx;
-    a.tb = 0.f;
-  }
-}
-
-DEVINL void test_sph2_any(const DevSph (&s)[2], int idx, f3 o, f3 L, Any &a) {
-  float b[2], q[2];
+template <typename V, int NV, int NB>
+DEVINL void test_sph_any(const DevSph (&s)[NB], int idx, const V3<V> (&o)[NV],
+                         const V3<V> (&L)[NV], Any (&a)[NV * lanes_of<V>::n]) {
+  constexpr int LN = lanes_of<V>::n;
+  V b[NV][NB], q[NV][NB];
+  float m = -1.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const f3 oc = mk(o.x - s[i].cx, o.y - s[i].cy, o.z - s[i].cz);
-    b[i] = dot(oc, L);
-    q[i] = b[i] * b[i] - (dot(oc, oc) - s[i].r2);
-  }
-  if (__builtin_amdgcn_ballot_w64(!(fmaxf(q[0], q[1]) < 0.f))) {
-    accept_sph_any(b[0], q[0], idx, a);
-    accept_sph_any(b[1], q[1], idx + 1, a);
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const V3<V> oc = sub_u(o[j], mk(s[i].cx, s[i].cy, s[i].cz));
+      b[j][i] = dotv(oc, L[j]);
+      q[j][i] = b[j][i] * b[j][i] - (dotv(oc, oc) - s[i].r2);
+#pragma unroll
+      for (int c = 0; c < LN; ++c) m = fmaxf(m, comp(q[j][i], c));
+    }
+  if (__builtin_amdgcn_ballot_w64(!(m < 0.f))) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int c = 0; c < LN; ++c)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          Any &aa = a[j * LN + c];
+          float t2;
+          if (sph_exact(comp(b[j][i], c), comp(q[j][i], c), aa.tb, t2)) {
+            aa.tocc = t2;
+            aa.kocc = idx + i;
+            aa.tb = 0.f;
+          }
+        }
   }
 }
 
-template <typename Fetch>
-DEVINL void anyhit_sph(Fetch rec, int n, int base, f3 o, f3 L, Any &a) {
+template <typename V, int NV, typename Fetch>
+DEVINL void anyhit_sph(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V3<V> (&L)[NV],
+                       Any (&a)[NV * lanes_of<V>::n]) {
   for (int k0 = 0; k0 < n; k0 += kExitStride) {
-    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return;
+    if (!any_looking(a)) return;
     const int m = min(kExitStride, n - k0);
     const int m4 = m & ~3;
     if (m4) {
@@ -348,17 +455,14 @@ DEVINL void anyhit_sph(Fetch rec, int n, int base, f3 o, f3 L, Any &a) {
       fetch_batch(rec, k0, A);
       for (int k = 0; k < m4; k += 4) {
         fetch_batch(rec, rec.landed(A[1].r2, k0 + k + 2), B);
-        test_sph2_any(A, base + k0 + k, o, L, a);
+        test_sph_any<V, NV, 2>(A, base + k0 + k, o, L, a);
         fetch_batch(rec, rec.landed(B[1].r2, k0 + min(k + 4, m - 2)), A);
-        test_sph2_any(B, base + k0 + k + 2, o, L, a);
+        test_sph_any<V, NV, 2>(B, base + k0 + k + 2, o, L, a);
       }
     }
     for (int k = m4; k < m; ++k) {
-      const DevSph s0 = rec(k0 + k);
-      const f3 oc = mk(o.x - s0.cx, o.y - s0.cy, o.z - s0.cz);
-      const float b0 = dot(oc, L);
-      const float q0 = b0 * b0 - (dot(oc, oc) - s0.r2);
-      accept_sph_any(b0, q0, base + k0 + k, a);
+      const DevSph s0[1] = {rec(k0 + k)};
+      test_sph_any<V, NV, 1>(s0, base + k0 + k, o, L, a);
     }
   }
 }
@@ -412,18 +516,21 @@ DEVINL uint32_t face_hash(uint64_t seed, uint32_t pixel, uint32_t light, uint32_
 }
 
 // ---------------------------------------------------------------------------------------
-// the frame kernel
+// the frame kernel.  256 threads = 4 waves; a wave covers a (16*PX) x 4 pixel block, the
+// workgroup a (32*PX) x 8 tile (2 x 2 waves).
 // ---------------------------------------------------------------------------------------
-template <int STAGE>
+template <int STAGE, typename V, int NV>
 __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
+  constexpr int PX = NV * lanes_of<V>::n; // pixels per work-item
+  constexpr int TW = 32 * PX;             // tile width
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
-  __shared__ float lds_px[kTileW * kTileH * 3];
+  __shared__ float lds_px[TW * kTileH * 3];
 
   // ---- workgroup -> pixel tile.  Blocks are dealt round-robin over the 8 XCDs, so block b
   // and b+8 share an L2; give each XCD one contiguous run of tiles (= contiguous framebuffer
   // rows) instead of every 8th tile.  Grid is padded to a multiple of 8; surplus blocks exit.
   const int rows = p.n_local_rows;
-  const int tiles_x = (p.W + kTileW - 1) / kTileW;
+  const int tiles_x = (p.W + TW - 1) / TW;
   const int tiles_y = (rows + kTileH - 1) / kTileH;
   const int n_tiles = tiles_x * tiles_y;
   const int per_xcd = gridDim.x >> 3;
@@ -433,9 +540,9 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int lx = ((wave & 1) << 4) + (lane & 15);
+  const int lx0 = (wave & 1) * (16 * PX) + (lane & 15); // pixel q of this lane: lx0 + 16 q
   const int ly = ((wave >> 1) << 2) + (lane >> 4);
-  const int w = tx * kTileW + lx;
+  const int w0 = tx * TW;
   // local row lr (ascending h) -> image row h.  A contiguous band has strip_rows >= its
   // height, so lr / strip_rows == 0 and h = h0 + lr; cyclic strips (multi-GPU) jump by
   // strip_step image rows per strip.  strip_rows is a multiple of kTileH (host-checked).
@@ -443,22 +550,32 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
   const int h_tile = p.h0 + (lr0 / p.strip_rows) * p.strip_step + (lr0 % p.strip_rows);
   const int lr = lr0 + ly;
   const int h = h_tile + ly;
-  const bool inside = (w < p.W) && (lr < rows) && (h < p.H);
+  const bool row_ok = (lr < rows) && (h < p.H);
 
   // ---- main.cpp:709-713 + camera.h:31-34
   const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
-  const float is = (float)w / (float)(p.W - 1);
   const float it = (float)h / (float)(p.H - 1);
-  const f3 dir = normalize(((ld3(p.llc) + ld3(p.horizontal) * is) + ld3(p.vertical) * it) - origin);
+  int w[PX];
+  bool inside[PX];
+  f3 dir[PX];
+  Hit hit[PX];
+#pragma unroll
+  for (int q = 0; q < PX; ++q) {
+    w[q] = w0 + lx0 + 16 * q;
+    inside[q] = row_ok && (w[q] < p.W);
+    const float is = (float)w[q] / (float)(p.W - 1);
+    dir[q] = normalize(((ld3(p.llc) + ld3(p.horizontal) * is) + ld3(p.vertical) * it) - origin);
+    hit[q].t = FLT_MAX; // main.cpp:715
+    hit[q].v = 0.f;
+    hit[q].idx = -1;
+  }
 
   // ---- main.cpp:722 closest hit over every primitive
-  Hit hit;
-  hit.t = FLT_MAX;
-  hit.v = 0.f;
-  hit.idx = -1;
+  V3<V> dv[NV];
+  pack3<V, NV>(dir, dv);
   if (STAGE == STAGE_SMEM) {
-    closest_tri_primary(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dir, hit);
-    closest_sph_primary(SmemFetch<DevSphP>{p.sph_p}, p.n_sph, p.n_tri, dir, hit);
+    closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dv, hit);
+    closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p}, p.n_sph, p.n_tri, dv, hit);
   } else {
     constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTriP);
     for (int k0 = 0; k0 < p.n_tri; k0 += CT) {
@@ -466,8 +583,8 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
       __syncthreads();
       lds_stage(reinterpret_cast<DevTriP *>(lds_raw), p.tri_p + k0, n);
       __syncthreads();
-      closest_tri_primary(LdsFetch<DevTriP>{reinterpret_cast<const DevTriP *>(lds_raw)}, n, k0,
-                          dir, hit);
+      closest_tri_primary<V, NV>(LdsFetch<DevTriP>{reinterpret_cast<const DevTriP *>(lds_raw)},
+                                 n, k0, dv, hit);
     }
     constexpr int CS = kLdsChunkBytes / (int)sizeof(DevSphP);
     for (int k0 = 0; k0 < p.n_sph; k0 += CS) {
@@ -475,73 +592,80 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
       __syncthreads();
       lds_stage(reinterpret_cast<DevSphP *>(lds_raw), p.sph_p + k0, n);
       __syncthreads();
-      closest_sph_primary(LdsFetch<DevSphP>{reinterpret_cast<const DevSphP *>(lds_raw)}, n,
-                          p.n_tri + k0, dir, hit);
+      closest_sph_primary<V, NV>(LdsFetch<DevSphP>{reinterpret_cast<const DevSphP *>(lds_raw)},
+                                 n, p.n_tri + k0, dv, hit);
     }
   }
-  const bool has_hit = inside && (hit.idx >= 0);
 
-  // ---- main.cpp:723-738 normal and material of the hit (per-lane gathers, once per pixel)
-  f3 N = mk(0.f, 0.f, 0.f);
-  f3 ka = N, kd = N, ks = N, ke = N;
-  float Ns = 0.f;
-  if (has_hit) {
-    int mi;
-    if (hit.idx < p.n_tri) {
-      const DevTri T = p.tri[hit.idx];
-      N = normalize(cross(ld3(T.e1), ld3(T.e2))); // :728-731
-      mi = T.geom;
-      if (p.mat[mi].has_normals) { // :733-738 with u == 0 (quirk S1)
-        const DevTriN Q = p.tri_n[hit.idx];
-        const float u = 0.f, v = hit.v;
-        N = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
+  // ---- main.cpp:723-738 normal of the hit (per-lane gathers, once per pixel)
+  bool has_hit[PX];
+  f3 N[PX];
+  int mi[PX];
+  float t[PX], r[PX], g[PX], b[PX];
+#pragma unroll
+  for (int q = 0; q < PX; ++q) {
+    has_hit[q] = inside[q] && (hit[q].idx >= 0);
+    N[q] = mk(0.f, 0.f, 0.f);
+    mi[q] = 0;
+    t[q] = hit[q].t;
+    r[q] = g[q] = b[q] = 0.f; // vec3 default ctor, main.cpp:557-558
+    if (has_hit[q]) {
+      if (hit[q].idx < p.n_tri) {
+        const DevTri T = p.tri[hit[q].idx];
+        N[q] = normalize(cross(ld3(T.e1), ld3(T.e2))); // :728-731
+        mi[q] = T.geom;
+        if (p.mat[mi[q]].has_normals) { // :733-738 with u == 0 (quirk S1)
+          const DevTriN Q = p.tri_n[hit[q].idx];
+          const float u = 0.f, v = hit[q].v;
+          N[q] = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
+        }
+      } else {
+        const int k = hit[q].idx - p.n_tri;
+        const DevSph S = p.sph[k];
+        N[q] = normalize((origin + dir[q] * hit[q].t) - mk(S.cx, S.cy, S.cz)); // extension
+        mi[q] = p.sph_mat[k];
       }
-    } else {
-      const int k = hit.idx - p.n_tri;
-      const DevSph S = p.sph[k];
-      N = normalize((origin + dir * hit.t) - mk(S.cx, S.cy, S.cz)); // extension
-      mi = p.sph_mat[k];
     }
-    const DevMat M = p.mat[mi];
-    ka = ld3(M.ka);
-    kd = ld3(M.kd);
-    ks = ld3(M.ks);
-    ke = ld3(M.ke);
-    Ns = M.Ns;
   }
 
   // ---- main.cpp:740-789 per-light shading
-  float r = 0.f, g = 0.f, b = 0.f; // vec3 default ctor, main.cpp:557-558
-  float t = hit.t;
   const float nl = (float)p.n_lights;
   uint32_t n_shadow = 0;
   unsigned long long n_any = 0; // any-hit tests the reference would have executed
   for (int li = 0; li < p.n_lights; ++li) {
     const DevLight Lt = p.lights[li];
-    f3 hp = N, L = N;
-    Any a;
-    a.tb = 0.f;
-    a.tocc = 0.f;
-    a.kocc = -1;
-    if (has_hit) {
-      uint32_t face = (p.face_mode == 0)
-                          ? (uint32_t)p.fixed_face
-                          : face_hash(p.seed, (uint32_t)(h * p.W + w), (uint32_t)li,
-                                      (uint32_t)Lt.n_faces);
-      const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
-      hp = origin + dir * (t - FLT_EPSILON); // :757-758
-      L = P - hp;                            // :759
-      const float len = length(L);           // :761
-      t = len - FLT_EPSILON;                 // :764
-      L = normalize(L);                      // :766
-      a.tb = t;
+    Any a[PX];
+    f3 ro[PX], rL[PX]; // shadow-ray origin (main.cpp:757 `hit`) and unit direction
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      ro[q] = N[q];
+      rL[q] = N[q];
+      a[q].tb = 0.f;
+      a[q].tocc = 0.f;
+      a[q].kocc = -1;
+      if (has_hit[q]) {
+        const uint32_t face =
+            (p.face_mode == 0) ? (uint32_t)p.fixed_face
+                               : face_hash(p.seed, (uint32_t)(h * p.W + w[q]), (uint32_t)li,
+                                           (uint32_t)Lt.n_faces);
+        const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
+        ro[q] = origin + dir[q] * (t[q] - FLT_EPSILON); // :757-758
+        rL[q] = P - ro[q];                              // :759
+        const float len = length(rL[q]);                // :761
+        t[q] = len - FLT_EPSILON;                       // :764
+        rL[q] = normalize(rL[q]);                       // :766
+        a[q].tb = t[q];
+      }
+      if (!(a[q].tb > 0.f)) a[q].tb = 0.f; // dead rays carry tb = 0
     }
-    if (p.shadows) { // :772 occlusion(): wave-uniform loops, dead lanes carry tb = 0
-      if (!(a.tb > 0.f)) a.tb = 0.f;
+    if (p.shadows) { // :772 occlusion(): wave-uniform loops
+      V3<V> ov[NV], Lv[NV];
+      pack3<V, NV>(ro, ov);
+      pack3<V, NV>(rL, Lv);
       if (STAGE == STAGE_SMEM) {
-        if (__builtin_amdgcn_ballot_w64(a.tb > 0.f)) {
-          anyhit_tri(SmemFetch<DevTri>{p.tri}, p.n_tri, 0, hp, L, a);
-          anyhit_sph(SmemFetch<DevSph>{p.sph}, p.n_sph, p.n_tri, hp, L, a);
+        if (any_looking(a)) {
+          anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri}, p.n_tri, 0, ov, Lv, a);
+          anyhit_sph<V, NV>(SmemFetch<DevSph>{p.sph}, p.n_sph, p.n_tri, ov, Lv, a);
         }
       } else {
         constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTri);
@@ -550,7 +674,8 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
           __syncthreads();
           lds_stage(reinterpret_cast<DevTri *>(lds_raw), p.tri + k0, n);
           __syncthreads();
-          anyhit_tri(LdsFetch<DevTri>{reinterpret_cast<const DevTri *>(lds_raw)}, n, k0, hp, L, a);
+          anyhit_tri<V, NV>(LdsFetch<DevTri>{reinterpret_cast<const DevTri *>(lds_raw)}, n, k0,
+                            ov, Lv, a);
         }
         constexpr int CS = kLdsChunkBytes / (int)sizeof(DevSph);
         for (int k0 = 0; k0 < p.n_sph; k0 += CS) {
@@ -558,39 +683,44 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
           __syncthreads();
           lds_stage(reinterpret_cast<DevSph *>(lds_raw), p.sph + k0, n);
           __syncthreads();
-          anyhit_sph(LdsFetch<DevSph>{reinterpret_cast<const DevSph *>(lds_raw)}, n,
-                     p.n_tri + k0, hp, L, a);
+          anyhit_sph<V, NV>(LdsFetch<DevSph>{reinterpret_cast<const DevSph *>(lds_raw)}, n,
+                            p.n_tri + k0, ov, Lv, a);
         }
-      }
-      if (has_hit) {
-        n_shadow += 1u;
-        // tests occlusion() runs for this ray: up to and including its first occluder
-        n_any += (a.kocc >= 0) ? (unsigned)(a.kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
       }
     }
-    if (has_hit) {
-      f3 c = (ka * 0.5f + ke) / nl; // :769-770
-      const bool occluded = p.shadows && (a.kocc >= 0);
-      if (occluded) {
-        t = a.tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
-      } else {
-        const float d = dot(N, L); // :775
-        if (!(d <= 0.f)) {         // :777
-          const f3 Hh = normalize((N + L) * 2.f); // :780
-          const float sp = powf(dot(N, Hh), Ns);
-          c = c + (kd * d + ks * sp) / nl; // :782-783
-          r += c.x;                        // :786-788
-          g += c.y;
-          b += c.z;
-        }
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      if (!has_hit[q]) continue;
+      if (p.shadows) {
+        n_shadow += 1u;
+        // tests occlusion() runs for this ray: up to and including its first occluder
+        n_any += (a[q].kocc >= 0) ? (unsigned)(a[q].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
       }
+      if (p.shadows && a[q].kocc >= 0) {
+        t[q] = a[q].tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
+        continue;         // :772-773
+      }
+      const float d = dot(N[q], rL[q]); // :775
+      if (d <= 0.f) continue;            // :777
+      const DevMat M = p.mat[mi[q]];     // :768
+      f3 c = (ld3(M.ka) * 0.5f + ld3(M.ke)) / nl; // :769-770
+      const f3 Hh = normalize((N[q] + rL[q]) * 2.f); // :780
+      const float sp = powf(dot(N[q], Hh), M.Ns);
+      c = c + (ld3(M.kd) * d + ld3(M.ks) * sp) / nl; // :782-783
+      r[q] += c.x;                                    // :786-788
+      g[q] += c.y;
+      b[q] += c.z;
     }
   }
 
   // ---- counters: one atomic per wave (ballot + popcount)
   if (p.counters) {
-    const uint64_t mi = __builtin_amdgcn_ballot_w64(inside);
-    const uint64_t mh = __builtin_amdgcn_ballot_w64(has_hit);
+    uint32_t ni = 0, nh = 0;
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      ni += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(inside[q]));
+      nh += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_hit[q]));
+    }
     uint32_t ns = n_shadow;
     unsigned long long na = n_any;
     for (int o = 32; o > 0; o >>= 1) {
@@ -598,60 +728,80 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
       na += __shfl_down(na, o);
     }
     if (lane == 0) {
-      atomicAdd(&p.counters[0], (unsigned long long)__popcll(mi));
-      atomicAdd(&p.counters[1], (unsigned long long)__popcll(mh));
+      atomicAdd(&p.counters[0], (unsigned long long)ni);
+      atomicAdd(&p.counters[1], (unsigned long long)nh);
       atomicAdd(&p.counters[2], (unsigned long long)ns);
       if (na) atomicAdd(&p.counters[3], na);
     }
   }
 
-  // ---- framebuffer: transpose the 32x8 tile through LDS so each store instruction writes
+  // ---- framebuffer: transpose the tile through LDS so each store instruction writes
   // consecutive dwords of one image row (12-byte pixels would otherwise stride the lanes).
-  const int w0 = tx * kTileW;
-  const bool full_tile = (w0 + kTileW <= p.W) && (lr0 + kTileH <= rows) && (h_tile + kTileH <= p.H);
+  const bool full_tile = (w0 + TW <= p.W) && (lr0 + kTileH <= rows) && (h_tile + kTileH <= p.H);
   if (p.out_f32) {
     if (full_tile) {
-      const int li = (ly * kTileW + lx) * 3;
-      lds_px[li + 0] = r;
-      lds_px[li + 1] = g;
-      lds_px[li + 2] = b;
+#pragma unroll
+      for (int q = 0; q < PX; ++q) {
+        const int li = (ly * TW + lx0 + 16 * q) * 3;
+        lds_px[li + 0] = r[q];
+        lds_px[li + 1] = g[q];
+        lds_px[li + 2] = b[q];
+      }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int idx = tid + 256 * i; // 0..767
-        const int row = idx / (kTileW * 3), col = idx % (kTileW * 3);
+      for (int i = 0; i < 3 * PX; ++i) {
+        const int idx = tid + 256 * i; // 0 .. TW*8*3-1
+        const int row = idx / (TW * 3), col = idx % (TW * 3);
         const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + col;
         p.out_f32[o] = lds_px[idx];
       }
-    } else if (inside) {
-      const size_t o = ((size_t)lr * p.W + w) * 3;
-      p.out_f32[o + 0] = r;
-      p.out_f32[o + 1] = g;
-      p.out_f32[o + 2] = b;
+    } else {
+#pragma unroll
+      for (int q = 0; q < PX; ++q)
+        if (inside[q]) {
+          const size_t o = ((size_t)lr * p.W + w[q]) * 3;
+          p.out_f32[o + 0] = r[q];
+          p.out_f32[o + 1] = g[q];
+          p.out_f32[o + 2] = b[q];
+        }
     }
   }
   if (p.out_u8) { // main.cpp:676-682 clamp > 1, int(c * 255)
-    const float cr = (r > 1.f) ? 1.f : r, cg = (g > 1.f) ? 1.f : g, cb = (b > 1.f) ? 1.f : b;
-    const uint8_t qr = (uint8_t)(int)(cr * 255.f), qg = (uint8_t)(int)(cg * 255.f),
-                  qb = (uint8_t)(int)(cb * 255.f);
+    uint8_t qr[PX], qg[PX], qb[PX];
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      const float cr = (r[q] > 1.f) ? 1.f : r[q], cg = (g[q] > 1.f) ? 1.f : g[q],
+                  cb = (b[q] > 1.f) ? 1.f : b[q];
+      qr[q] = (uint8_t)(int)(cr * 255.f);
+      qg[q] = (uint8_t)(int)(cg * 255.f);
+      qb[q] = (uint8_t)(int)(cb * 255.f);
+    }
     if (full_tile && (p.W & 3) == 0) {
       __syncthreads(); // lds_px reuse
       unsigned char *lb = reinterpret_cast<unsigned char *>(lds_px);
-      const int li = (ly * kTileW + lx) * 3;
-      lb[li + 0] = qr;
-      lb[li + 1] = qg;
-      lb[li + 2] = qb;
-      __syncthreads();
-      if (tid < kTileW * kTileH * 3 / 4) { // 192 dwords
-        const int row = tid / (kTileW * 3 / 4), col = tid % (kTileW * 3 / 4);
-        const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + (size_t)col * 4;
-        *reinterpret_cast<uint32_t *>(p.out_u8 + o) = reinterpret_cast<const uint32_t *>(lb)[tid];
+#pragma unroll
+      for (int q = 0; q < PX; ++q) {
+        const int li = (ly * TW + lx0 + 16 * q) * 3;
+        lb[li + 0] = qr[q];
+        lb[li + 1] = qg[q];
+        lb[li + 2] = qb[q];
       }
-    } else if (inside) {
-      const size_t o = ((size_t)lr * p.W + w) * 3;
-      p.out_u8[o + 0] = qr;
-      p.out_u8[o + 1] = qg;
-      p.out_u8[o + 2] = qb;
+      __syncthreads();
+      constexpr int ROW_DW = TW * 3 / 4; // dwords per tile row
+      for (int i = tid; i < ROW_DW * kTileH; i += 256) {
+        const int row = i / ROW_DW, col = i % ROW_DW;
+        const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + (size_t)col * 4;
+        *reinterpret_cast<uint32_t *>(p.out_u8 + o) = reinterpret_cast<const uint32_t *>(lb)[i];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < PX; ++q)
+        if (inside[q]) {
+          const size_t o = ((size_t)lr * p.W + w[q]) * 3;
+          p.out_u8[o + 0] = qr[q];
+          p.out_u8[o + 1] = qg[q];
+          p.out_u8[o + 2] = qb[q];
+        }
     }
   }
 }
@@ -712,16 +862,28 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
   return (int)hipGetLastError();
 }
 
-extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, hipStream_t stream) {
+template <int STAGE, typename V, int NV>
+static int launch_render_variant(const esc::RenderParams *p, hipStream_t stream) {
   const int rows = p->n_local_rows;
-  if (rows <= 0 || p->W <= 0) return 0;
-  const int tiles_x = (p->W + esc::kTileW - 1) / esc::kTileW;
+  const int tw = 32 * NV * esc::lanes_of<V>::n;
+  const int tiles_x = (p->W + tw - 1) / tw;
   const int tiles_y = (rows + esc::kTileH - 1) / esc::kTileH;
   const int n_tiles = tiles_x * tiles_y;
   const int grid = ((n_tiles + 7) / 8) * 8;
-  if (stage == esc::STAGE_LDS)
-    hipLaunchKernelGGL(esc::k_render<esc::STAGE_LDS>, dim3(grid), dim3(256), 0, stream, *p);
-  else
-    hipLaunchKernelGGL(esc::k_render<esc::STAGE_SMEM>, dim3(grid), dim3(256), 0, stream, *p);
+  hipLaunchKernelGGL((esc::k_render<STAGE, V, NV>), dim3(grid), dim3(256), 0, stream, *p);
   return (int)hipGetLastError();
+}
+
+// stage: 1 SMEM, 2 LDS.  px: pixels per lane (1, 2 or 4).
+extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, hipStream_t stream) {
+  if (p->n_local_rows <= 0 || p->W <= 0) return 0;
+  using esc::v2f;
+  if (stage == esc::STAGE_LDS) {
+    if (px == 1) return launch_render_variant<esc::STAGE_LDS, float, 1>(p, stream);
+    if (px == 2) return launch_render_variant<esc::STAGE_LDS, v2f, 1>(p, stream);
+    return launch_render_variant<esc::STAGE_LDS, v2f, 2>(p, stream);
+  }
+  if (px == 1) return launch_render_variant<esc::STAGE_SMEM, float, 1>(p, stream);
+  if (px == 2) return launch_render_variant<esc::STAGE_SMEM, v2f, 1>(p, stream);
+  return launch_render_variant<esc::STAGE_SMEM, v2f, 2>(p, stream);
 }

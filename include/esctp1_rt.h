@@ -192,6 +192,10 @@ typedef struct {
   int32_t fixed_face;
   int32_t stage; /* ESC_STAGE_* */
   uint64_t seed;
+  int32_t pixels_per_lane; /* 0 = auto; 1, 2 or 4 pixels carried by each work-item (same row,
+                              16 columns apart).  Purely a scheduling choice: results are
+                              bit-identical for every value. */
+  int32_t reserved;
 } esc_render_options;
 
 typedef struct {

@@ -41,22 +41,24 @@ def render_both(esc, renderer, d, eye, look, W, H, **kw):
     renderer.upload(sc)
     cam = esc.Camera.for_image(eye, look, W, H)
     okw = {k: v for k, v in kw.items() if k in ("shadows", "face_mode", "fixed_face", "seed")}
+    # the product's ESC_FACE_* / the checker's ORC_FACE_* share values 0 / 1
     ref = ol.oracle_render(d, eye, look, W, H, threads=8, **okw)
     gpu, u8 = renderer.render(cam, W, H, want_u8=True, **kw)
     return gpu, u8, ref
 
 
 # ---------------------------------------------------------------- reference-pinned scenes
+@pytest.mark.parametrize("px", [1, 2, 4])
 @pytest.mark.parametrize("stage", ["smem", "lds"])
 @pytest.mark.parametrize("name,eye", [("one", (0, 1, 3)), ("two", (0, 1, 3)),
                                       ("CornellBox-Original", (0, 1, 2)),
                                       ("CornellBox-Empty-CO", (0, 1, 3)),
                                       ("cornell_box", (0, 1, 3))])
-def test_triangle_scenes_bit_exact(esc, renderer, name, eye, stage):
+def test_triangle_scenes_bit_exact(esc, renderer, name, eye, stage, px):
     d = ol.load_dump(name)
     st = esc.ESC_STAGE_SMEM if stage == "smem" else esc.ESC_STAGE_LDS
-    gpu, u8, ref = render_both(esc, renderer, d, eye, (0, 1, 0), 160, 90, stage=st)
-    assert_bit_equal(gpu, ref, f"{name}/{stage}")
+    gpu, u8, ref = render_both(esc, renderer, d, eye, (0, 1, 0), 160, 90, stage=st, px=px)
+    assert_bit_equal(gpu, ref, f"{name}/{stage}/px{px}")
     assert np.array_equal(u8, ol.oracle_quantise(ref))
     assert ref.sum() > 0
 
@@ -123,10 +125,11 @@ def synthetic_dict(esc, config, n):
     return sc, ol.scene_from_product(sc)
 
 
+@pytest.mark.parametrize("px", [1, 2, 4])
 @pytest.mark.parametrize("stage", ["smem", "lds"])
 @pytest.mark.parametrize("config,n,shadows", [("c2", 100, False), ("c3", 1000, True),
                                               ("c4", 613, True), ("c4", 10000, True)])
-def test_sphere_scenes_bit_exact(esc, renderer, config, n, shadows, stage):
+def test_sphere_scenes_bit_exact(esc, renderer, config, n, shadows, stage, px):
     sc, d = synthetic_dict(esc, config, n)
     eye, look = esc.synthetic_view()
     W, H = (192, 108) if n < 5000 else (96, 54)
@@ -134,11 +137,11 @@ def test_sphere_scenes_bit_exact(esc, renderer, config, n, shadows, stage):
     cam = esc.Camera.for_image(eye, look, W, H)
     st = esc.ESC_STAGE_SMEM if stage == "smem" else esc.ESC_STAGE_LDS
     renderer.reset_counters()
-    gpu, u8 = renderer.render(cam, W, H, want_u8=True, shadows=shadows, stage=st)
+    gpu, u8 = renderer.render(cam, W, H, want_u8=True, shadows=shadows, stage=st, px=px)
     cnt = renderer.counters()
     ref, rc = ol.oracle_render(d, eye, look, W, H, shadows=shadows, threads=8,
                                return_counters=True)
-    assert_bit_equal(gpu, ref, f"{config}/{n}/{stage}")
+    assert_bit_equal(gpu, ref, f"{config}/{n}/{stage}/px{px}")
     assert np.array_equal(u8, ol.oracle_quantise(ref))
     assert cnt == rc
     assert 0 < rc["hit_pixels"] < W * H
@@ -152,8 +155,10 @@ def test_mixed_triangles_and_spheres(esc, renderer):
     mats = np.stack([ol.material13(ka=c, kd=c) for c in rng.uniform(0.2, 0.9, (40, 3))])
     d2 = ol.scene_dict(d["geometry"], sph, mats)
     for stage in (esc.ESC_STAGE_SMEM, esc.ESC_STAGE_LDS):
-        gpu, u8, ref = render_both(esc, renderer, d2, (0, 1, 3), (0, 1, 0), 160, 90, stage=stage)
-        assert_bit_equal(gpu, ref, "mixed")
+        for px in (1, 2, 4):
+            gpu, u8, ref = render_both(esc, renderer, d2, (0, 1, 3), (0, 1, 0), 160, 90,
+                                       stage=stage, px=px)
+            assert_bit_equal(gpu, ref, f"mixed/px{px}")
 
 
 def test_heightfield_c5_small(esc, renderer):
@@ -168,12 +173,13 @@ def test_heightfield_c5_small(esc, renderer):
 
 
 # ---------------------------------------------------------------- shapes, bands, drop-in
-@pytest.mark.parametrize("W,H", [(33, 9), (97, 61), (130, 75), (2, 2), (64, 8), (31, 7)])
-def test_ragged_sizes(esc, renderer, W, H):
+@pytest.mark.parametrize("px", [1, 2, 4])
+@pytest.mark.parametrize("W,H", [(33, 9), (97, 61), (130, 75), (2, 2), (64, 8), (31, 7), (128, 8)])
+def test_ragged_sizes(esc, renderer, W, H, px):
     """partial tiles in both directions, W % 4 != 0 (byte-store path of the u8 output)"""
     d = ol.load_dump("one")
-    gpu, u8, ref = render_both(esc, renderer, d, (0, 1, 3), (0, 1, 0), W, H)
-    assert_bit_equal(gpu, ref, f"{W}x{H}")
+    gpu, u8, ref = render_both(esc, renderer, d, (0, 1, 3), (0, 1, 0), W, H, px=px)
+    assert_bit_equal(gpu, ref, f"{W}x{H}/px{px}")
     assert np.array_equal(u8, ol.oracle_quantise(ref))
 
 

@@ -18,16 +18,19 @@ r.upload(sc)
 eye, look = esc.synthetic_view()
 cam = esc.Camera.for_image(eye, look, W, H)
 buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
-variants = [("smem", esc.ESC_STAGE_SMEM, True), ("lds", esc.ESC_STAGE_LDS, True),
-            ("smem-noshadow", esc.ESC_STAGE_SMEM, False), ("lds-noshadow", esc.ESC_STAGE_LDS, False)]
+variants = []
+for px in (1, 2, 4):
+    variants += [(f"smem px{px}", esc.ESC_STAGE_SMEM, True, px), (f"lds px{px}", esc.ESC_STAGE_LDS, True, px),
+                 (f"smem px{px} noshadow", esc.ESC_STAGE_SMEM, False, px),
+                 (f"lds px{px} noshadow", esc.ESC_STAGE_LDS, False, px)]
 res = {v[0]: [] for v in variants}
 for rd in range(rounds + 1):
-    for name, stage, sh in variants:
+    for name, stage, sh, px in variants:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r.reset_counters()
         with torch.cuda.stream(st):
             e0.record(st)
-            r.render_rows(cam, W, H, 0, H, out_f32=buf, stage=stage, shadows=sh)
+            r.render_rows(cam, W, H, 0, H, out_f32=buf, stage=stage, shadows=sh, px=px)
             e1.record(st)
         st.synchronize()
         if rd:
@@ -37,4 +40,4 @@ rays = c["primary_rays"] + c["shadow_rays"]
 print("counters(last variant)", c)
 for k, v in res.items():
     v.sort()
-    print(f"{k:16s} min {v[0]:9.3f} ms  med {v[len(v)//2]:9.3f} ms")
+    print(f"{k:22s} min {v[0]:9.3f} ms  med {v[len(v)//2]:9.3f} ms")

@@ -1,0 +1,131 @@
+// Microbenchmark: what wave64 VALU issue rate does gfx950 actually sustain for the instruction
+// mix of k_render's inner loops (v_mul_f32 / v_add_f32 / v_sub_f32, no FMA, SGPR operands)?
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize valu_rate.hip -o valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// MODE 0: independent mul/add on VGPRs only (8 accumulators)
+// MODE 1: the primary sphere test body on SGPR operands, records from a uniform pointer (s_load), no branch
+// MODE 2: MODE 1 + the max/cmp/branch filter (never taken)
+// MODE 3: same as 2 but table in LDS (ds_read_b128 broadcast)
+template <int MODE>
+__global__ void __launch_bounds__(256) k(const float4 *__restrict__ tab, int n, int iters, float *out,
+                                         float dx, float dy, float dz) {
+  __shared__ float4 lds[2048];
+  float acc = 0.f;
+  float x = dx + threadIdx.x * 1e-6f, y = dy, z = dz;
+  if (MODE == 3) {
+    for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = tab[i];
+    __syncthreads();
+  }
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+      float a0 = x, a1 = y, a2 = z, a3 = x + 1.f, a4 = y + 1.f, a5 = z + 1.f, a6 = x + 2.f, a7 = y + 2.f;
+      for (int k = 0; k < n; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a0 = a0 * x; a1 = a1 + y; a2 = a2 * z; a3 = a3 + x;
+          a4 = a4 * y; a5 = a5 + z; a6 = a6 * x; a7 = a7 + y;
+        }
+      }
+      acc += a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    } else {
+      for (int k = 0; k < n; k += 4) {
+        float4 s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] = (MODE == 3) ? lds[(k + u) & 2047] : tab[k + u];
+        float q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float b = (s[u].x * x + s[u].y * y) + s[u].z * z;
+          q[u] = b * b - s[u].w;
+        }
+        if (MODE >= 2) {
+          float m = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
+          if (__builtin_amdgcn_ballot_w64(!(m < 0.f))) acc += sqrtf(q[0]) + sqrtf(q[1]) + sqrtf(q[2]) + sqrtf(q[3]);
+        } else {
+          acc += q[0]; acc += q[1]; acc += q[2]; acc += q[3];
+        }
+      }
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// MODE 4: packed fp32 (v_pk_mul_f32 / v_pk_add_f32), 8 independent float2 accumulators
+__global__ void __launch_bounds__(256) kpk(int n, int iters, float *out, float dx, float dy) {
+  float acc = 0.f;
+  v2f x = {dx + threadIdx.x * 1e-6f, dx * 0.5f}, y = {dy, dy * 2.f};
+  for (int it = 0; it < iters; ++it) {
+    v2f a0 = x, a1 = y, a2 = x + 1.f, a3 = y + 1.f, a4 = x + 2.f, a5 = y + 2.f, a6 = x + 3.f, a7 = y + 3.f;
+    for (int k = 0; k < n; k += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 = a0 * x; a1 = a1 + y; a2 = a2 * y; a3 = a3 + x;
+        a4 = a4 * y; a5 = a5 + x; a6 = a6 * x; a7 = a7 + y;
+      }
+    }
+    v2f t = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    acc += t.x + t.y;
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+int run_pk(float *d_out, int n, int iters, int blocks) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kpk, dim3(blocks), dim3(256), 0, 0, n, 1, d_out, 0.3f, 0.5f);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kpk, dim3(blocks), dim3(256), 0, 0, n, iters, d_out, 0.3f, 0.5f);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double wave_instr = (double)blocks * 4 * iters * (n / 4.0) * 32;
+  double per = wave_instr / 1024.0 / (ms * 1e3);
+  printf("%-28s blocks %6d  %8.3f ms  %6.1f PK wave-instr/us/SIMD  -> %.2f cycles/instr @2.4GHz (%.1f Tlane-op/s, 2 ops per pk lane)\n",
+         "mode4 v_pk mul/add x32", blocks, ms, per, 2400.0 / per, wave_instr * 128 / (ms * 1e-3) / 1e12);
+  return 0;
+}
+
+template <int MODE> int run(const char *name, int valu_per_4, const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d_tab, n, 1, d_out, 0.3f, 0.5f, -0.8f);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d_tab, n, iters, d_out, 0.3f, 0.5f, -0.8f);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double waves = (double)blocks * 4;
+  double wave_instr = waves * iters * (n / 4.0) * valu_per_4;
+  double per_simd_per_us = wave_instr / 1024.0 / (ms * 1e3);
+  printf("%-28s blocks %6d  %8.3f ms  %6.1f VALU wave-instr/us/SIMD  -> %.2f cycles/instr @2.4GHz (%.1f Tlane-op/s)\n",
+         name, blocks, ms, per_simd_per_us, 2400.0 / per_simd_per_us, wave_instr * 64 / (ms * 1e-3) / 1e12);
+  return 0;
+}
+
+int main() {
+  const int n = 10000;
+  std::vector<float4> h(n);
+  for (int i = 0; i < n; i++) h[i] = make_float4(0.01f * i, 1.f, 2.f, 1e9f);
+  float4 *d_tab; float *d_out;
+  CHECK(hipMalloc((void **)&d_tab, n * sizeof(float4)));
+  CHECK(hipMalloc((void **)&d_out, 4));
+  CHECK(hipMemcpy(d_tab, h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  for (int blocks : {1024, 2048, 16384}) {
+    int iters = 16384 * 8 / blocks; if (iters < 1) iters = 1; if (iters > 64) iters = 64;
+    if (run<0>("mode0 vgpr mul/add x32", 32, d_tab, d_out, n, iters, blocks)) return 1;
+    if (run<1>("mode1 sphere body smem", 32, d_tab, d_out, n, iters, blocks)) return 1;
+    if (run<2>("mode2 +filter/branch smem", 31, d_tab, d_out, n, iters, blocks)) return 1;
+    if (run<3>("mode3 +filter/branch lds", 31, d_tab, d_out, n, iters, blocks)) return 1;
+    if (run_pk(d_out, n, iters, blocks)) return 1;
+  }
+  return 0;
+}
