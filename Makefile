@@ -28,7 +28,7 @@ $(LIB): $(LIB_SRC) $(LIB_HDR)
 
 viewer: $(VIEWER)
 
-$(VIEWER): $(PKG)/host/viewer_main.cpp $(LIB)
+$(VIEWER): $(PKG)/host/viewer_main.cpp include/esctp1_rt.h $(LIB)
 	@mkdir -p bin
 	$(HIPCC) -O2 -std=c++17 -ffp-contract=off -Iinclude -o $@ $(PKG)/host/viewer_main.cpp \
 	    -L$(LIBDIR) -lesctp1rt -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'

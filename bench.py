@@ -65,6 +65,18 @@ CONFIGS = {  # BASELINE.json configs 2-5 -> (W, H, shadows)
 }
 
 
+def host_cores():
+    """cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(scene, eye, look, W, H, shadows, n_rows, gpu_frame):
     """oracle on evenly spaced rows of the same frame, all host cores; also a free parity
     spot-check of the GPU frame on those rows"""
@@ -75,7 +87,7 @@ def cpu_baseline(scene, eye, look, W, H, shadows, n_rows, gpu_frame):
 
     d = ol.OracleScene(ol.scene_from_product(scene))
     rows = sorted({min(H - 1, int((i + 0.5) * H / n_rows)) for i in range(n_rows)})
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     t0 = time.perf_counter()
     img, cnt = ol.oracle_render_rows(d, eye, look, W, H, rows, shadows=shadows, threads=cores)
     dt = time.perf_counter() - t0
@@ -225,6 +237,8 @@ def main():
                 "primary_rays_per_frame": primary / a.steps,
                 "shadow_rays_per_frame": shadow / a.steps,
                 "hit_pixels_per_frame": hits / a.steps,
+                "closest_hit_tests_per_frame": primary / a.steps * (n_tri + n_sph),
+                "anyhit_tests_per_frame": anyhit / a.steps,
             },
             "kernel": {"name": "k_render", "avg_ms": kernel_ms,
                        "launches_timed": len(events), "rank": 0, "rows": my_rows},

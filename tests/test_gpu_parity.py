@@ -90,6 +90,39 @@ def test_one_1024x768_ppm_md5(esc, renderer, tmp_path):
     assert p2.read_bytes() == p.read_bytes()
 
 
+def test_config1_default_scene_full_size(esc, renderer):
+    """BASELINE.json config 1: CornellBox-Original, eye 0,1,2, look 0,1,0, 1024x768
+    (scripts/run.sh:28-30; geometry = what the reference's loader returns)."""
+    d = ol.load_dump("CornellBox-Original")
+    gpu, u8, ref = render_both(esc, renderer, d, (0, 1, 2), (0, 1, 0), 1024, 768,
+                               face_mode=esc.ESC_FACE_HASH, seed=0)
+    assert_bit_equal(gpu, ref, "config 1")
+    assert np.array_equal(u8, ol.oracle_quantise(ref))
+    assert int((ref.sum(axis=2) > 0).sum()) > 300000
+
+
+def test_viewer_binary_modes(esc, tmp_path, golden_dir):
+    """bin/ESCViewer2021 through every mode flag of scripts/run.sh: identical PPM, equal to the
+    library's frame (the --ispc mode goes through flatten + the `trace` symbol)."""
+    import os
+    import subprocess
+    exe = os.path.join(ol.ROOT, "bin", "ESCViewer2021")
+    if not os.path.exists(exe):
+        pytest.skip("viewer not built")
+    obj = os.path.join(golden_dir, "scenes", "one.obj")
+    outs = []
+    for i, flags in enumerate(([], ["--thread"], ["--bvh"], ["--ispc"], ["--gpus", "3"])):
+        out = tmp_path / f"o{i}.ppm"
+        r = subprocess.run([exe, "-m", obj, "-v", "0,1,3", "-l", "0,1,0", "-o", str(out)] + flags,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Duration" in r.stderr and "Rendered image in:" in r.stdout
+        outs.append(out.read_bytes())
+    assert all(o == outs[0] for o in outs)
+    import hashlib
+    assert hashlib.md5(outs[0]).hexdigest() == "b10e1cb14f839129bd111670002cfb0b"
+
+
 def test_multi_face_light_hash_and_membership(esc, renderer):
     """2-face light (every bundled Cornell scene): hashed face choice matches the oracle bit
     for bit, and each pixel equals the face-0 or the face-1 render."""
