@@ -274,6 +274,120 @@ DEVINL void closest_tri_primary(Fetch rec, int n, int base, const V3<V> (&d)[NV]
   }
 }
 
+// ---- hand-scheduled packed-fp32 bodies (2 pixels per lane, SGPR operands) ----------------------
+// hipcc's own v2f code for these tests spends a v_mov per hi-half broadcast and serialises the
+// dependent v_pk chains (s_nop hazards); measured, it is no faster than scalar code.  Written by
+// hand: every sphere constant is read straight from its SGPR pair through op_sel (lo or hi half
+// to both lanes), the independent chains of the batch are interleaved so no v_pk result is
+// consumed by the next instruction, and nothing but v_pk_mul_f32 / v_pk_add_f32 (with neg
+// modifiers, which are exact) is used -- each half rounds exactly like the scalar v_mul / v_add /
+// v_sub of the generic path, in the same order.
+// The "any candidate?" filter works on the raw bits: a value is non-negative iff its bit
+// pattern is >= 0 as a signed int (a disc of -0 cannot occur: b*b is >= +0 and x - x = +0).
+struct SphP2 { // DevSphP seen as two aligned pairs: (ocx, ocy), (ocz, cc)
+  v2f xy, zc;
+};
+struct Sph2 { // DevSph: (cx, cy), (cz, r2)
+  v2f xy, zr;
+};
+
+DEVINL int max3i(int a, int b, int c) { return max(max(a, b), c); }
+DEVINL bool any_nonneg(v2f a, v2f b, v2f c, v2f d) {
+  int m = max3i(__float_as_int(a.x), __float_as_int(a.y), __float_as_int(b.x));
+  m = max3i(m, __float_as_int(b.y), __float_as_int(c.x));
+  m = max3i(m, __float_as_int(c.y), __float_as_int(d.x));
+  m = max(m, __float_as_int(d.y));
+  return m >= 0;
+}
+
+// primary rays, 4 spheres x 2 pixels: b = (ocx*dx + ocy*dy) + ocz*dz ; q = b*b - cc
+DEVINL void sph4_primary_pk(const SphP2 (&s)[4], v2f dx, v2f dy, v2f dz, v2f (&b)[4], v2f (&q)[4]) {
+  asm("v_pk_mul_f32 %0, %[s0a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %1, %[s1a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %2, %[s2a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %3, %[s3a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %4, %[s0a], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %5, %[s1a], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %6, %[s2a], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %7, %[s3a], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_add_f32 %0, %0, %4\n\t"
+      "v_pk_add_f32 %1, %1, %5\n\t"
+      "v_pk_add_f32 %2, %2, %6\n\t"
+      "v_pk_add_f32 %3, %3, %7\n\t"
+      "v_pk_mul_f32 %4, %[s0b], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %5, %[s1b], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %6, %[s2b], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %7, %[s3b], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, %4\n\t"
+      "v_pk_add_f32 %1, %1, %5\n\t"
+      "v_pk_add_f32 %2, %2, %6\n\t"
+      "v_pk_add_f32 %3, %3, %7\n\t"
+      "v_pk_mul_f32 %4, %0, %0\n\t"
+      "v_pk_mul_f32 %5, %1, %1\n\t"
+      "v_pk_mul_f32 %6, %2, %2\n\t"
+      "v_pk_mul_f32 %7, %3, %3\n\t"
+      "v_pk_add_f32 %4, %4, %[s0b] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %5, %5, %[s1b] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %6, %6, %[s2b] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %7, %7, %[s3b] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]),
+        "=&v"(q[3])
+      : [x] "v"(dx), [y] "v"(dy), [z] "v"(dz), [s0a] "s"(s[0].xy), [s0b] "s"(s[0].zc),
+        [s1a] "s"(s[1].xy), [s1b] "s"(s[1].zc), [s2a] "s"(s[2].xy), [s2b] "s"(s[2].zc),
+        [s3a] "s"(s[3].xy), [s3b] "s"(s[3].zc));
+}
+
+// shadow rays, 2 spheres x 2 pixels:
+//   oc = o - c ; b = (ocx*Lx + ocy*Ly) + ocz*Lz ; cc = ((ocx*ocx + ocy*ocy) + ocz*ocz) - r2 ;
+//   q = b*b - cc
+DEVINL void sph2_any_pk(const Sph2 (&s)[2], v2f ox, v2f oy, v2f oz, v2f Lx, v2f Ly, v2f Lz,
+                        v2f (&b)[2], v2f (&q)[2]) {
+  v2f ax, ay, az, bx, by, bz, t0, t1; // oc of sphere A / B, temporaries
+  asm("v_pk_add_f32 %[ax], %[ox], %[sAxy] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bx], %[ox], %[sBxy] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay], %[oy], %[sAxy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[by], %[oy], %[sBxy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az], %[oz], %[sAzr] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bz], %[oz], %[sBzr] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      // b = dot(oc, L)
+      "v_pk_mul_f32 %[bA], %[ax], %[Lx]\n\t"
+      "v_pk_mul_f32 %[bB], %[bx], %[Lx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[Ly]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[Ly]\n\t"
+      "v_pk_add_f32 %[bA], %[bA], %[t0]\n\t"
+      "v_pk_add_f32 %[bB], %[bB], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[Lz]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[Lz]\n\t"
+      "v_pk_add_f32 %[bA], %[bA], %[t0]\n\t"
+      "v_pk_add_f32 %[bB], %[bB], %[t1]\n\t"
+      // dot(oc, oc)
+      "v_pk_mul_f32 %[qA], %[ax], %[ax]\n\t"
+      "v_pk_mul_f32 %[qB], %[bx], %[bx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[ay]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[by]\n\t"
+      "v_pk_add_f32 %[qA], %[qA], %[t0]\n\t"
+      "v_pk_add_f32 %[qB], %[qB], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[az]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[bz]\n\t"
+      "v_pk_add_f32 %[qA], %[qA], %[t0]\n\t"
+      "v_pk_add_f32 %[qB], %[qB], %[t1]\n\t"
+      // cc = dot - r2
+      "v_pk_add_f32 %[qA], %[qA], %[sAzr] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[qB], %[qB], %[sBzr] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      // q = b*b - cc
+      "v_pk_mul_f32 %[t0], %[bA], %[bA]\n\t"
+      "v_pk_mul_f32 %[t1], %[bB], %[bB]\n\t"
+      "v_pk_add_f32 %[qA], %[t0], %[qA] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[qB], %[t1], %[qB] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [bA] "=&v"(b[0]), [bB] "=&v"(b[1]), [qA] "=&v"(q[0]), [qB] "=&v"(q[1]), [ax] "=&v"(ax),
+        [ay] "=&v"(ay), [az] "=&v"(az), [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz),
+        [t0] "=&v"(t0), [t1] "=&v"(t1)
+      : [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [Lx] "v"(Lx), [Ly] "v"(Ly), [Lz] "v"(Lz),
+        [sAxy] "s"(s[0].xy), [sAzr] "s"(s[0].zr), [sBxy] "s"(s[1].xy), [sBzr] "s"(s[1].zr));
+}
+
 // ---- closest hit, primary rays, spheres ---------------------------------------------------
 template <typename V, int NV, int NB>
 DEVINL void test_sph_primary(const DevSphP (&s)[NB], int idx, const V3<V> (&d)[NV],
@@ -324,6 +438,38 @@ DEVINL void closest_sph_primary(Fetch rec, int n, int base, const V3<V> (&d)[NV]
   for (int k = n8; k < n; ++k) {
     const DevSphP s0[1] = {rec(k)};
     test_sph_primary<V, NV, 1>(s0, base + k, d, h);
+  }
+}
+
+// SMEM + 2 pixels per lane: the hand-scheduled packed body above
+template <typename Fetch>
+DEVINL void closest_sph_primary_pk(Fetch rec, int n, int base, const V3<v2f> &d, Hit (&h)[2]) {
+  auto test4 = [&](const SphP2(&S)[4], int idx) {
+    v2f b[4], q[4];
+    sph4_primary_pk(S, d.x, d.y, d.z, b, q);
+    if (__builtin_amdgcn_ballot_w64(any_nonneg(q[0], q[1], q[2], q[3]))) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t2;
+          if (sph_exact(comp(b[i], c), comp(q[i], c), h[c].t, t2)) {
+            h[c].t = t2;
+            h[c].idx = idx + i;
+          }
+        }
+    }
+  };
+  const int n8 = n & ~7;
+  if (n8) {
+    SphP2 A[4], B[4];
+    fetch_batch(rec, 0, A);
+    for (int k = 0; k < n8; k += 8) {
+      fetch_batch(rec, rec.landed(A[3].zc, k + 4), B);
+      test4(A, base + k);
+      fetch_batch(rec, rec.landed(B[3].zc, min(k + 8, n - 4)), A);
+      test4(B, base + k + 4);
+    }
   }
 }
 
@@ -467,6 +613,44 @@ DEVINL void anyhit_sph(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V
   }
 }
 
+// SMEM + 2 pixels per lane: hand-scheduled packed body, 2 spheres per batch
+template <typename Fetch>
+DEVINL void anyhit_sph_pk(Fetch rec, int n, int base, const V3<v2f> &o, const V3<v2f> &L,
+                          Any (&a)[2]) {
+  auto test2 = [&](const Sph2(&S)[2], int idx) {
+    v2f b[2], q[2];
+    sph2_any_pk(S, o.x, o.y, o.z, L.x, L.y, L.z, b, q);
+    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                      __float_as_int(q[1].y));
+    if (__builtin_amdgcn_ballot_w64(m >= 0)) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float t2;
+          if (sph_exact(comp(b[i], c), comp(q[i], c), a[c].tb, t2)) {
+            a[c].tocc = t2;
+            a[c].kocc = idx + i;
+            a[c].tb = 0.f;
+          }
+        }
+    }
+  };
+  // n is a multiple of 4 here (the caller peels the remainder)
+  for (int k0 = 0; k0 < n; k0 += kExitStride) {
+    if (!any_looking(a)) return;
+    const int m = min(kExitStride, n - k0);
+    Sph2 A[2], B[2];
+    fetch_batch(rec, k0, A);
+    for (int k = 0; k < m; k += 4) {
+      fetch_batch(rec, rec.landed(A[1].zr, k0 + k + 2), B);
+      test2(A, base + k0 + k);
+      fetch_batch(rec, rec.landed(B[1].zr, k0 + min(k + 4, m - 2)), A);
+      test2(B, base + k0 + k + 2);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // staging front-ends
 // ---------------------------------------------------------------------------------------
@@ -484,6 +668,10 @@ template <typename Rec> struct SmemFetch {
   // The index of the next fetch is threaded through the same asm so the s_load cannot be
   // hoisted above it.
   DEVINL int landed(float &x, int next_k) const {
+    asm("" : "+s"(x), "+s"(next_k));
+    return next_k;
+  }
+  DEVINL int landed(v2f &x, int next_k) const {
     asm("" : "+s"(x), "+s"(next_k));
     return next_k;
   }
@@ -575,7 +763,16 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
   pack3<V, NV>(dir, dv);
   if (STAGE == STAGE_SMEM) {
     closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dv, hit);
-    closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p}, p.n_sph, p.n_tri, dv, hit);
+    if constexpr (PX == 2) {
+      // multiples of 8 through the hand-scheduled packed body, the tail through the generic one
+      const int n8 = p.n_sph & ~7;
+      closest_sph_primary_pk(SmemFetch<SphP2>{reinterpret_cast<const SphP2 *>(p.sph_p)}, n8,
+                             p.n_tri, dv[0], hit);
+      closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p + n8}, p.n_sph - n8, p.n_tri + n8, dv,
+                                 hit);
+    } else {
+      closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p}, p.n_sph, p.n_tri, dv, hit);
+    }
   } else {
     constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTriP);
     for (int k0 = 0; k0 < p.n_tri; k0 += CT) {
@@ -665,7 +862,14 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
       if (STAGE == STAGE_SMEM) {
         if (any_looking(a)) {
           anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri}, p.n_tri, 0, ov, Lv, a);
-          anyhit_sph<V, NV>(SmemFetch<DevSph>{p.sph}, p.n_sph, p.n_tri, ov, Lv, a);
+          if constexpr (PX == 2) {
+            const int n4 = p.n_sph & ~3;
+            anyhit_sph_pk(SmemFetch<Sph2>{reinterpret_cast<const Sph2 *>(p.sph)}, n4, p.n_tri,
+                          ov[0], Lv[0], a);
+            anyhit_sph<V, NV>(SmemFetch<DevSph>{p.sph + n4}, p.n_sph - n4, p.n_tri + n4, ov, Lv, a);
+          } else {
+            anyhit_sph<V, NV>(SmemFetch<DevSph>{p.sph}, p.n_sph, p.n_tri, ov, Lv, a);
+          }
         }
       } else {
         constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTri);

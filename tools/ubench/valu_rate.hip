@@ -93,6 +93,76 @@ int run_pk(float *d_out, int n, int iters, int blocks) {
   return 0;
 }
 
+// MODE 5: the primary sphere test for 2 pixels per lane, 4 spheres per block, hand-written:
+// packed fp32 with the sphere constants read straight from SGPR pairs through op_sel (no moves),
+// the four independent chains interleaved so no v_pk result is consumed by the next instruction.
+__global__ void __launch_bounds__(256) kasm(const float4 *__restrict__ tab, int n, int iters, float *out,
+                                            float dx, float dy, float dz) {
+  float acc = 0.f;
+  v2f x = {dx + threadIdx.x * 1e-6f, dx * 0.5f}, y = {dy, dy * 2.f}, z = {dz, dz * 0.25f};
+  for (int it = 0; it < iters; ++it) {
+    for (int k = 0; k < n; k += 4) {
+      float4 s0 = tab[k], s1 = tab[k + 1], s2 = tab[k + 2], s3 = tab[k + 3];
+      v2f q0, q1, q2, q3, t0, t1, t2, t3;
+      float m;
+      asm volatile(
+          "v_pk_mul_f32 %0, %[s0xy], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+          "v_pk_mul_f32 %1, %[s1xy], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+          "v_pk_mul_f32 %2, %[s2xy], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+          "v_pk_mul_f32 %3, %[s3xy], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+          "v_pk_mul_f32 %4, %[s0xy], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+          "v_pk_mul_f32 %5, %[s1xy], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+          "v_pk_mul_f32 %6, %[s2xy], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+          "v_pk_mul_f32 %7, %[s3xy], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+          "v_pk_add_f32 %0, %0, %4\n\t"
+          "v_pk_add_f32 %1, %1, %5\n\t"
+          "v_pk_add_f32 %2, %2, %6\n\t"
+          "v_pk_add_f32 %3, %3, %7\n\t"
+          "v_pk_mul_f32 %4, %[s0zw], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+          "v_pk_mul_f32 %5, %[s1zw], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+          "v_pk_mul_f32 %6, %[s2zw], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+          "v_pk_mul_f32 %7, %[s3zw], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+          "v_pk_add_f32 %0, %0, %4\n\t"
+          "v_pk_add_f32 %1, %1, %5\n\t"
+          "v_pk_add_f32 %2, %2, %6\n\t"
+          "v_pk_add_f32 %3, %3, %7\n\t"
+          "v_pk_mul_f32 %4, %0, %0\n\t"
+          "v_pk_mul_f32 %5, %1, %1\n\t"
+          "v_pk_mul_f32 %6, %2, %2\n\t"
+          "v_pk_mul_f32 %7, %3, %3\n\t"
+          "v_pk_add_f32 %4, %4, %[s0zw] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %5, %5, %[s1zw] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %6, %6, %[s2zw] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %7, %7, %[s3zw] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+          : [x] "v"(x), [y] "v"(y), [z] "v"(z),
+            [s0xy] "s"(*(const v2f *)&s0.x), [s0zw] "s"(*(const v2f *)&s0.z),
+            [s1xy] "s"(*(const v2f *)&s1.x), [s1zw] "s"(*(const v2f *)&s1.z),
+            [s2xy] "s"(*(const v2f *)&s2.x), [s2zw] "s"(*(const v2f *)&s2.z),
+            [s3xy] "s"(*(const v2f *)&s3.x), [s3zw] "s"(*(const v2f *)&s3.z));
+      m = fmaxf(fmaxf(fmaxf(q0.x, q0.y), fmaxf(q1.x, q1.y)), fmaxf(fmaxf(q2.x, q2.y), fmaxf(q3.x, q3.y)));
+      if (__builtin_amdgcn_ballot_w64(!(m < 0.f)))
+        acc += sqrtf(q0.x) + sqrtf(q1.y) + sqrtf(q2.x) + sqrtf(q3.y) + t0.x + t1.y + t2.x + t3.y;
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+int run_asm(const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kasm, dim3(blocks), dim3(256), 0, 0, d_tab, n, 1, d_out, 0.3f, 0.5f, -0.8f);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kasm, dim3(blocks), dim3(256), 0, 0, d_tab, n, iters, d_out, 0.3f, 0.5f, -0.8f);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double tests = (double)blocks * 4 * iters * n * 128.0;  // pixel-tests
+  printf("%-28s blocks %6d  %8.3f ms  %.1f Gtests/s (pixel x sphere)\n", "mode5 asm pk smem px2", blocks, ms, tests / (ms * 1e-3) / 1e9);
+  return 0;
+}
+
 template <int MODE> int run(const char *name, int valu_per_4, const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -106,8 +176,9 @@ template <int MODE> int run(const char *name, int valu_per_4, const float4 *d_ta
   double waves = (double)blocks * 4;
   double wave_instr = waves * iters * (n / 4.0) * valu_per_4;
   double per_simd_per_us = wave_instr / 1024.0 / (ms * 1e3);
-  printf("%-28s blocks %6d  %8.3f ms  %6.1f VALU wave-instr/us/SIMD  -> %.2f cycles/instr @2.4GHz (%.1f Tlane-op/s)\n",
-         name, blocks, ms, per_simd_per_us, 2400.0 / per_simd_per_us, wave_instr * 64 / (ms * 1e-3) / 1e12);
+  printf("%-28s blocks %6d  %8.3f ms  %6.1f VALU wave-instr/us/SIMD  -> %.2f cycles/instr @2.4GHz (%.1f Tlane-op/s) %.1f Gtests/s\n",
+         name, blocks, ms, per_simd_per_us, 2400.0 / per_simd_per_us, wave_instr * 64 / (ms * 1e-3) / 1e12,
+         waves * iters * (double)n * 64.0 / (ms * 1e-3) / 1e9);
   return 0;
 }
 
@@ -126,6 +197,7 @@ int main() {
     if (run<2>("mode2 +filter/branch smem", 31, d_tab, d_out, n, iters, blocks)) return 1;
     if (run<3>("mode3 +filter/branch lds", 31, d_tab, d_out, n, iters, blocks)) return 1;
     if (run_pk(d_out, n, iters, blocks)) return 1;
+    if (run_asm(d_tab, d_out, n, iters, blocks)) return 1;
   }
   return 0;
 }
