@@ -54,6 +54,11 @@ def parse():
                     help="what rank 0 collects: fp32 RGB (the seam's return_image) or PPM bytes")
     ap.add_argument("--cpu-rows", type=int, default=128,
                     help="rows of the frame the CPU baseline renders (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo lets several ranks share one GPU to rehearse the N>1 path")
+    ap.add_argument("--verify-rows", type=int, default=0,
+                    help="N>1: rank 0 checks this many rows of the assembled frame against the "
+                         "test oracle after the timed region")
     return ap.parse_args()
 
 
@@ -115,10 +120,14 @@ def main():
               f"torch.distributed.run for N>1", file=sys.stderr)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the renderer has no CPU path")
+    local_rank %= torch.cuda.device_count()  # gloo rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     W0, H0, shadows = CONFIGS[a.config]
     W, H = a.width or W0, a.height or H0
@@ -137,50 +146,77 @@ def main():
     max_rows = multigpu.max_local_rows(H, world, S)
     use_u8 = a.gather == "u8"
     ch_dtype = torch.uint8 if use_u8 else torch.float32
-    local = torch.zeros(max_rows * W * 3, dtype=ch_dtype, device=dev)
-    gathered = frame = None
-    if world > 1 and rank == 0:
-        gathered = torch.zeros(world, max_rows * W * 3, dtype=ch_dtype, device=dev)
-        frame = torch.zeros(H * W * 3, dtype=ch_dtype, device=dev)
+    n_local = max_rows * W * 3
+    # N>1: two strip buffers so the gather of frame i (second stream) overlaps the render of
+    # frame i+1; rank 0 assembles on that second stream through its own context
+    n_buf = 2 if world > 1 else 1
+    local = [torch.zeros(n_local, dtype=ch_dtype, device=dev) for _ in range(n_buf)]
+    gathered = frame = r2 = st2 = None
+    if world > 1:
+        st2 = torch.cuda.Stream(device=dev)
+        if rank == 0:
+            gathered = [torch.zeros(world, n_local, dtype=ch_dtype, device=dev) for _ in range(n_buf)]
+            frame = torch.zeros(H * W * 3, dtype=ch_dtype, device=dev)
+            r2 = esc.Renderer(local_rank, stream=st2)
+    buf_free = [None] * n_buf  # event: the gather that last read local[b] has finished
 
     events = []
 
-    def step(timed):
+    def step(i, timed):
+        b = i % n_buf
         with torch.cuda.stream(st):
+            if buf_free[b] is not None:
+                st.wait_event(buf_free[b])
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(st)
-            r.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local,
-                            out_u8=local if use_u8 else None, strip_rows=S, shadows=shadows,
+            r.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
+                            out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows,
                             stage=stage)
             e1.record(st)
             if timed:
                 events.append((e0, e1))
-            if world > 1:
-                multigpu.gather_to_root(local, rank, world, gathered)
+        if world > 1:
+            with torch.cuda.stream(st2):
+                st2.wait_event(e1)  # the collective orders itself after the current stream
+                multigpu.gather_to_root(local[b], rank, world, gathered[b] if rank == 0 else None)
                 if rank == 0:
-                    r.assemble_strips(gathered, world, max_rows * W * 3 * local.element_size(), W,
-                                      H, frame, strip_rows=S, bytes_per_pixel=3 * local.element_size())
+                    r2.assemble_strips(gathered[b], world, n_local * local[b].element_size(), W, H,
+                                       frame, strip_rows=S,
+                                       bytes_per_pixel=3 * local[b].element_size())
+                ev = torch.cuda.Event()
+                ev.record(st2)
+                buf_free[b] = ev
 
     def fence():
         st.synchronize()
+        if st2 is not None:
+            st2.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step(False)
+    for i in range(a.warmup):
+        step(i, False)
     fence()
     r.reset_counters()
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
+    for i in range(a.steps):
+        step(i, True)
     fence()
     elapsed = time.perf_counter() - t0
+    cnt = r.counters()  # rays of exactly the K timed frames
 
-    cnt = r.counters()
+    # one un-pipelined frame: launch -> complete frame resident on rank 0
+    fence()
+    t1 = time.perf_counter()
+    step(0, False)
+    fence()
+    frame_latency_ms = (time.perf_counter() - t1) * 1e3
+    r.synchronize()
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     c = torch.tensor([cnt["primary_rays"], cnt["shadow_rays"], cnt["anyhit_tests"],
                       cnt["hit_pixels"]], dtype=torch.float64, device=dev)
@@ -195,7 +231,7 @@ def main():
         rays = primary + shadow
         n_tri, n_sph = info["n_triangles"], info["n_spheres"]
         # ---- roofline of the dominant kernel (k_render) on THIS rank's launch
-        frame_bytes = my_rows * W * 3 * local.element_size()
+        frame_bytes = my_rows * W * 3 * local[0].element_size()
         scene_bytes = n_sph * 32 + n_tri * 112 + (info["n_geometry"] + n_sph) * 64
         alg_bytes = frame_bytes + scene_bytes
         gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -217,6 +253,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
+            "frame_latency_ms": frame_latency_ms,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -230,8 +267,9 @@ def main():
                 "scene": "esc_scene_synthetic (SURVEY.md 8(d)): splitmix64 seeds 0xC2..0xC4",
                 "partition": f"{S}-row strips round-robin over {world} rank(s)",
                 "gather": ("none (1 GPU)" if world == 1 else
-                           f"RCCL gather of {'u8' if use_u8 else 'fp32'} RGB strips to rank 0 "
-                           f"+ k_assemble_strips"),
+                           f"{'RCCL' if a.backend == 'nccl' else 'gloo'} gather of "
+                           f"{'u8' if use_u8 else 'fp32'} RGB strips to rank 0 + k_assemble_strips, "
+                           f"on a second stream overlapping the next frame's render"),
                 "stage": a.stage,
                 "rays_per_frame": rays / a.steps,
                 "primary_rays_per_frame": primary / a.steps,
@@ -255,11 +293,22 @@ def main():
         if world == 1 and a.cpu_rows > 0:
             gpu_frame = None
             if not use_u8:
-                gpu_frame = local[:H * W * 3].cpu().numpy().reshape(H, W, 3)
+                gpu_frame = local[0][:H * W * 3].cpu().numpy().reshape(H, W, 3)
             cb, same = cpu_baseline(scene, eye, look, W, H, shadows, a.cpu_rows, gpu_frame)
             out["cpu_baseline"] = cb
             out["gpu_vs_cpu"] = out["value"] / cb["value"]
             out["parity_sample_rows_bit_exact"] = same
+        if world > 1 and a.verify_rows > 0 and not use_u8:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import numpy as np
+
+            import oracle_lib as ol
+            rows = sorted({min(H - 1, int((i + 0.5) * H / a.verify_rows)) for i in range(a.verify_rows)})
+            ref, _ = ol.oracle_render_rows(ol.scene_from_product(scene), eye, look, W, H, rows,
+                                           shadows=shadows, threads=host_cores())
+            got = frame.view(H, W, 3)[rows].cpu().numpy()
+            out["assembled_frame_rows_bit_exact"] = bool(
+                np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -177,7 +177,8 @@ def synthetic_view():
 
 def _options(shadows, face_mode, fixed_face, seed, stage, px=0):
     o = _capi.esc_render_options()
-    o.pixels_per_lane = px
+    o.pixels_per_lane = px % 100
+    o.reserved = px // 100  # developer experiments (kernel variants); 0 in normal use
     o.shadows = 1 if shadows else 0
     o.face_mode = face_mode
     o.fixed_face = fixed_face

@@ -420,6 +420,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.face_mode = opts->face_mode;
   p.fixed_face = opts->fixed_face;
   p.seed = opts->seed;
+  p.pad0 = opts->reserved;
   p.out_f32 = d_rgb_f32;
   p.out_u8 = d_rgb_u8;
   p.counters = ctx->d_counters;

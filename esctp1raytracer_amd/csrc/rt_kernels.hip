@@ -592,21 +592,24 @@ DEVINL void test_sph_any(const DevSph (&s)[NB], int idx, const V3<V> (&o)[NV],
 template <typename V, int NV, typename Fetch>
 DEVINL void anyhit_sph(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V3<V> (&L)[NV],
                        Any (&a)[NV * lanes_of<V>::n]) {
+  // 4 spheres per fetch (one s_load_dwordx16): scalar loads return out of order, so only ONE
+  // fetch can be in flight behind the one being consumed; a longer block hides more latency
+  constexpr int NB = (NV * lanes_of<V>::n == 1) ? 4 : 2;
   for (int k0 = 0; k0 < n; k0 += kExitStride) {
     if (!any_looking(a)) return;
     const int m = min(kExitStride, n - k0);
-    const int m4 = m & ~3;
-    if (m4) {
-      DevSph A[2], B[2];
+    const int mb = m - m % (2 * NB);
+    if (mb) {
+      DevSph A[NB], B[NB];
       fetch_batch(rec, k0, A);
-      for (int k = 0; k < m4; k += 4) {
-        fetch_batch(rec, rec.landed(A[1].r2, k0 + k + 2), B);
-        test_sph_any<V, NV, 2>(A, base + k0 + k, o, L, a);
-        fetch_batch(rec, rec.landed(B[1].r2, k0 + min(k + 4, m - 2)), A);
-        test_sph_any<V, NV, 2>(B, base + k0 + k + 2, o, L, a);
+      for (int k = 0; k < mb; k += 2 * NB) {
+        fetch_batch(rec, rec.landed(A[NB - 1].r2, k0 + k + NB), B);
+        test_sph_any<V, NV, NB>(A, base + k0 + k, o, L, a);
+        fetch_batch(rec, rec.landed(B[NB - 1].r2, k0 + min(k + 2 * NB, m - NB)), A);
+        test_sph_any<V, NV, NB>(B, base + k0 + k + NB, o, L, a);
       }
     }
-    for (int k = m4; k < m; ++k) {
+    for (int k = mb; k < m; ++k) {
       const DevSph s0[1] = {rec(k0 + k)};
       test_sph_any<V, NV, 1>(s0, base + k0 + k, o, L, a);
     }
@@ -728,8 +731,12 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int lx0 = (wave & 1) * (16 * PX) + (lane & 15); // pixel q of this lane: lx0 + 16 q
-  const int ly = ((wave >> 1) << 2) + (lane >> 4);
+  int lx0 = (wave & 1) * (16 * PX) + (lane & 15); // pixel q of this lane: lx0 + 16 q
+  int ly = ((wave >> 1) << 2) + (lane >> 4);
+  if (PX == 1 && p.pad0 == 1) { // experiment: 8x8 wave footprint, waves side by side
+    lx0 = wave * 8 + (lane & 7);
+    ly = lane >> 3;
+  }
   const int w0 = tx * TW;
   // local row lr (ascending h) -> image row h.  A contiguous band has strip_rows >= its
   // height, so lr / strip_rows == 0 and h = h0 + lr; cyclic strips (multi-GPU) jump by
