@@ -15,7 +15,8 @@
 #include "rt_device.h"
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
-                                  esc::DevSphP *sph_p, hipStream_t stream);
+                                  esc::DevSphP *sph_p, esc::DevSphPairP *sph2_p,
+                                  hipStream_t stream);
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px,
                                  hipStream_t stream);
 extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
@@ -43,6 +44,8 @@ struct esc_context {
   esc::DevTriN *d_tri_n = nullptr;
   esc::DevSph *d_sph = nullptr;
   esc::DevSphP *d_sph_p = nullptr;
+  esc::DevSphPair *d_sph2 = nullptr;
+  esc::DevSphPairP *d_sph2_p = nullptr;
   int32_t *d_sph_mat = nullptr;
   esc::DevMat *d_mat = nullptr;
   esc::DevLight *d_lights = nullptr;
@@ -233,11 +236,24 @@ template <typename T> int alloc_dev(T *&dptr, size_t n) {
 
 int commit(esc_context *ctx, const Staged &s) {
   HIP_TRY(hipSetDevice(ctx->device));
+  // pair-interleaved copy of the sphere table (rt_device.h DevSphPair)
+  std::vector<esc::DevSphPair> sph2((s.sph.size() + 1) / 2);
+  for (size_t j = 0; j < sph2.size(); j++)
+    for (int h = 0; h < 2; h++) {
+      const size_t k = 2 * j + h;
+      const bool real = k < s.sph.size();
+      sph2[j].cx[h] = real ? s.sph[k].cx : 0.f;
+      sph2[j].cy[h] = real ? s.sph[k].cy : 0.f;
+      sph2[j].cz[h] = real ? s.sph[k].cz : 0.f;
+      sph2[j].r2[h] = real ? s.sph[k].r2 : -__builtin_huge_valf(); // cc = +inf: never hit
+    }
   HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read old tables
   int rc;
   if ((rc = upload_vec(ctx->d_tri, s.tri, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_tri_n, s.tri_n, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph, s.sph, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_sph2, sph2, ctx->stream))) return rc;
+  if ((rc = alloc_dev(ctx->d_sph2_p, sph2.size()))) return rc;
   if ((rc = upload_vec(ctx->d_sph_mat, s.sph_mat, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_mat, s.mat, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_lights, s.lights, ctx->stream))) return rc;
@@ -286,8 +302,8 @@ int esc_context_create(int32_t device, esc_context **out) {
     return ESC_ERR_HIP;
   }
   ctx->own_stream = true;
-  hipError_t ce = hipMalloc((void **)&ctx->d_counters, 4 * sizeof(unsigned long long));
-  if (ce == hipSuccess) ce = hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long));
+  hipError_t ce = hipMalloc((void **)&ctx->d_counters, 8 * sizeof(unsigned long long));
+  if (ce == hipSuccess) ce = hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long));
   if (ce != hipSuccess) {
     set_error(std::string("hipMalloc(counters): ") + hipGetErrorString(ce));
     esc_context_destroy(ctx);
@@ -302,6 +318,7 @@ void esc_context_destroy(esc_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
+                  ctx->d_sph2,   ctx->d_sph2_p,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8};
   for (void *p : ptrs)
@@ -412,6 +429,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.tri_n = ctx->d_tri_n;
   p.sph = ctx->d_sph;
   p.sph_p = ctx->d_sph_p;
+  p.sph2 = ctx->d_sph2;
+  p.sph2_p = ctx->d_sph2_p;
   p.sph_mat = ctx->d_sph_mat;
   p.mat = ctx->d_mat;
   p.lights = ctx->d_lights;
@@ -426,7 +445,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.counters = ctx->d_counters;
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
-    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_sph_p, ctx->stream);
+    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_sph_p, ctx->d_sph2_p, ctx->stream);
     if (e) {
       set_error(std::string("k_prepare_primary launch: ") + hipGetErrorString((hipError_t)e));
       return ESC_ERR_HIP;
@@ -522,7 +541,7 @@ int esc_reset_counters(esc_context *ctx) {
     return ESC_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
   return ESC_OK;
 }
 

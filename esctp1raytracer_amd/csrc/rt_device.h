@@ -43,6 +43,16 @@ struct alignas(16) DevSphP {
   float ocx, ocy, ocz, cc;
 };
 
+// Two spheres per record, component-interleaved, so each field is one aligned SGPR pair that
+// a v_pk_mul_f32 / v_pk_add_f32 consumes directly: sphere 2j in the low halves, 2j+1 in the high
+// halves.  Odd counts are padded with a sphere that can never be hit (cc = +inf).
+struct alignas(16) DevSphPair { // general form; pad half has r2 = -inf
+  float cx[2], cy[2], cz[2], r2[2];
+};
+struct alignas(16) DevSphPairP { // primary form (per frame)
+  float ocx[2], ocy[2], ocz[2], cc[2];
+};
+
 // scene.h:11-18 Material + whether the owning geometry has normals (main.cpp:733)
 struct alignas(16) DevMat {
   float ka[3];
@@ -84,6 +94,8 @@ struct RenderParams {
   const DevTriN *tri_n; // nullptr when no geometry has normals
   const DevSph *sph;
   const DevSphP *sph_p;
+  const DevSphPair *sph2;    // ceil(n_sph / 2) records
+  const DevSphPairP *sph2_p; // ceil(n_sph / 2) records
   const int32_t *sph_mat; // material index of sphere k (already offset by n_geom)
   const DevMat *mat;      // [n_geom + n_sphere_materials]
   const DevLight *lights;

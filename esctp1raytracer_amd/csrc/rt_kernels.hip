@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "rt_device.h"
 
@@ -153,8 +154,8 @@ DEVINL bool sph_exact(float b, float disc, float tbound, float &t2o) {
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, int n_tri,
-                  const DevSph *__restrict__ sph, DevSphP *__restrict__ sph_p, int n_sph,
-                  float ox, float oy, float oz) {
+                  const DevSph *__restrict__ sph, DevSphP *__restrict__ sph_p,
+                  DevSphPairP *__restrict__ sph2_p, int n_sph, float ox, float oy, float oz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const f3 o = mk(ox, oy, oz);
   if (i < n_tri) {
@@ -180,6 +181,15 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, i
     P.ocz = oc.z;
     P.cc = dot(oc, oc) - S.r2;
     sph_p[i] = P;
+    DevSphPairP &Q = sph2_p[i >> 1]; // same values, pair-interleaved (each thread owns a half)
+    Q.ocx[i & 1] = P.ocx;
+    Q.ocy[i & 1] = P.ocy;
+    Q.ocz[i & 1] = P.ocz;
+    Q.cc[i & 1] = P.cc;
+    if (i == n_sph - 1 && (n_sph & 1)) { // pad half: cc = +inf -> disc = -inf, never a candidate
+      Q.ocx[1] = Q.ocy[1] = Q.ocz[1] = 0.f;
+      Q.cc[1] = __builtin_huge_valf();
+    }
   }
 }
 
@@ -388,6 +398,142 @@ DEVINL void sph2_any_pk(const Sph2 (&s)[2], v2f ox, v2f oy, v2f oz, v2f Lx, v2f 
         [sAxy] "s"(s[0].xy), [sAzr] "s"(s[0].zr), [sBxy] "s"(s[1].xy), [sBzr] "s"(s[1].zr));
 }
 
+// ---- 1 pixel per lane, TWO SPHERES per packed op -------------------------------------------
+// Same idea with the roles swapped: the lane keeps one ray and the two halves of every v_pk op
+// hold spheres 2j and 2j+1, whose constants arrive pair-interleaved (DevSphPairP) and feed the
+// ops as plain SGPR pairs; the ray's components are broadcast to both halves through op_sel.
+// Measured on c4: primary pass 11.4 -> 10.4 ms.  The 32-op shadow body gains nothing by itself
+// (13.1 vs 12.6 ms scalar: its v_pk ops run at ~8 cycles instead of ~4, the register pairs hipcc
+// hands to an opaque asm collide in the VGPR banks), but it must be packed too: with a packed
+// primary pass and a SCALAR shadow pass sharing the SIMDs the frame took 30.9 ms (rocprofv3:
+// fewer VALU instructions, +48 % issue stalls), against 23.5 ms packed/packed and 24.0 ms
+// scalar/scalar.
+struct PairP { // DevSphPairP as four aligned pairs
+  v2f x, y, z, c;
+};
+struct PairG { // DevSphPair
+  v2f x, y, z, r;
+};
+
+// primary: b = (ocx*dx + ocy*dy) + ocz*dz ; q = b*b - cc, for records R0 (spheres 0,1), R1 (2,3)
+DEVINL void pair2_primary_pk(const PairP (&R)[2], v2f dxy, v2f dz_, v2f (&b)[2], v2f (&q)[2]) {
+  v2f t0, t1;
+  asm("v_pk_mul_f32 %[b0], %[r0x], %[dxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b1], %[r1x], %[dxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t0], %[r0y], %[dxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t1], %[r1y], %[dxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[r0z], %[dz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[r1z], %[dz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_mul_f32 %[q0], %[b0], %[b0]\n\t"
+      "v_pk_mul_f32 %[q1], %[b1], %[b1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[r0c] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[r1c] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [q0] "=&v"(q[0]), [q1] "=&v"(q[1]), [t0] "=&v"(t0),
+        [t1] "=&v"(t1)
+      : [dxy] "v"(dxy), [dz] "v"(dz_), [r0x] "s"(R[0].x), [r0y] "s"(R[0].y), [r0z] "s"(R[0].z),
+        [r0c] "s"(R[0].c), [r1x] "s"(R[1].x), [r1y] "s"(R[1].y), [r1z] "s"(R[1].z),
+        [r1c] "s"(R[1].c));
+}
+
+// shadow: oc = o - c ; b = (ocx*Lx + ocy*Ly) + ocz*Lz ; cc = ((ocx^2 + ocy^2) + ocz^2) - r2 ;
+// q = b*b - cc, for records R0 (spheres 0,1) and R1 (spheres 2,3)
+DEVINL void pair2_any_pk(const PairG (&R)[2], v2f oxy, v2f oz_, v2f Lxy, v2f Lz_, v2f (&b)[2],
+                         v2f (&q)[2]) {
+  v2f ax, ay, az, bx, by, bz, t0, t1;
+  asm("v_pk_add_f32 %[ax], %[oxy], %[r0x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bx], %[oxy], %[r1x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay], %[oxy], %[r0y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[by], %[oxy], %[r1y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az], %[oz], %[r0z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bz], %[oz], %[r1z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[b0], %[ax], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b1], %[bx], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_mul_f32 %[q0], %[ax], %[ax]\n\t"
+      "v_pk_mul_f32 %[q1], %[bx], %[bx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[ay]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[by]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[t0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[az]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[bz]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[t0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[t1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[r0r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[r1r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[t0], %[b0], %[b0]\n\t"
+      "v_pk_mul_f32 %[t1], %[b1], %[b1]\n\t"
+      "v_pk_add_f32 %[q0], %[t0], %[q0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[t1], %[q1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [q0] "=&v"(q[0]), [q1] "=&v"(q[1]), [ax] "=&v"(ax),
+        [ay] "=&v"(ay), [az] "=&v"(az), [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz),
+        [t0] "=&v"(t0), [t1] "=&v"(t1)
+      : [oxy] "v"(oxy), [oz] "v"(oz_), [Lxy] "v"(Lxy), [Lz] "v"(Lz_), [r0x] "s"(R[0].x),
+        [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0r] "s"(R[0].r), [r1x] "s"(R[1].x),
+        [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1r] "s"(R[1].r));
+}
+
+// closest hit over pair records [0, n_rec): each record = spheres base+2j, base+2j+1
+template <typename Fetch>
+DEVINL void closest_sph_primary_pairs(Fetch rec, int n_rec, int base, f3 d, Hit &h) {
+  const v2f dxy = {d.x, d.y}, dz_ = {d.z, 0.f};
+  auto test = [&](const PairP(&R)[2], int idx) {
+    v2f b[2], q[2];
+    pair2_primary_pk(R, dxy, dz_, b, q);
+    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                      __float_as_int(q[1].y));
+    if (__builtin_amdgcn_ballot_w64(m >= 0)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { // index order: record i, half c
+          float t2;
+          if (sph_exact(comp(b[i], c), comp(q[i], c), h.t, t2)) {
+            h.t = t2;
+            h.idx = idx + 2 * i + c;
+          }
+        }
+    }
+  };
+  const int n4 = n_rec & ~3;
+  if (n4) {
+    PairP A[2], B[2];
+    fetch_batch(rec, 0, A);
+    for (int k = 0; k < n4; k += 4) {
+      fetch_batch(rec, rec.landed(A[1].c, k + 2), B);
+      test(A, base + 2 * k);
+      fetch_batch(rec, rec.landed(B[1].c, min(k + 4, n_rec - 2)), A);
+      test(B, base + 2 * k + 4);
+    }
+  }
+  for (int k = n4; k < n_rec; ++k) { // < 4 records left: pair each with itself (idempotent)
+    const PairP R[2] = {rec(k), rec(k)};
+    v2f b[2], q[2];
+    pair2_primary_pk(R, dxy, dz_, b, q);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float t2;
+      if (sph_exact(comp(b[0], c), comp(q[0], c), h.t, t2)) {
+        h.t = t2;
+        h.idx = base + 2 * k + c;
+      }
+    }
+  }
+}
+
 // ---- closest hit, primary rays, spheres ---------------------------------------------------
 template <typename V, int NV, int NB>
 DEVINL void test_sph_primary(const DevSphP (&s)[NB], int idx, const V3<V> (&d)[NV],
@@ -485,6 +631,9 @@ struct Any {
   float tocc;
   int32_t kocc;
 };
+// Each check drains the fetch pipeline (the next block's s_load is re-issued cold), so it is
+// taken every 256 primitives, not more often: overshooting an exit by < 256 of 10^4..10^5
+// primitives costs far less than a cold scalar load per 32.
 constexpr int kExitStride = 32;
 
 template <int PX> DEVINL bool any_looking(const Any (&a)[PX]) {
@@ -654,6 +803,56 @@ DEVINL void anyhit_sph_pk(Fetch rec, int n, int base, const V3<v2f> &o, const V3
   }
 }
 
+// any-hit over pair records (1 pixel per lane, two spheres per packed op)
+constexpr int kPairExitRecords = 128; // exit check every 256 spheres (it drains the fetch pipeline)
+template <typename Fetch>
+DEVINL void anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a) {
+  const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
+  auto accept = [&](const v2f(&b)[2], const v2f(&q)[2], int idx, int nrec) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= nrec) break;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float t2;
+        if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2)) {
+          a.tocc = t2;
+          a.kocc = idx + 2 * i + c;
+          a.tb = 0.f;
+        }
+      }
+    }
+  };
+  auto test = [&](const PairG(&R)[2], int idx) {
+    v2f b[2], q[2];
+    pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                      __float_as_int(q[1].y));
+    if (__builtin_amdgcn_ballot_w64(m >= 0)) accept(b, q, idx, 2);
+  };
+  for (int k0 = 0; k0 < n_rec; k0 += kPairExitRecords) {
+    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return;
+    const int m = min(kPairExitRecords, n_rec - k0);
+    const int m4 = m & ~3;
+    if (m4) {
+      PairG A[2], B[2];
+      fetch_batch(rec, k0, A);
+      for (int k = 0; k < m4; k += 4) {
+        fetch_batch(rec, rec.landed(A[1].r, k0 + k + 2), B);
+        test(A, base + 2 * (k0 + k));
+        fetch_batch(rec, rec.landed(B[1].r, k0 + min(k + 4, m - 2)), A);
+        test(B, base + 2 * (k0 + k + 2));
+      }
+    }
+    for (int k = m4; k < m; ++k) {
+      const PairG R[2] = {rec(k0 + k), rec(k0 + k)};
+      v2f b[2], q[2];
+      pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+      accept(b, q, base + 2 * (k0 + k), 1);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // staging front-ends
 // ---------------------------------------------------------------------------------------
@@ -777,6 +976,9 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
                              p.n_tri, dv[0], hit);
       closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p + n8}, p.n_sph - n8, p.n_tri + n8, dv,
                                  hit);
+    } else if constexpr (PX == 1) {
+      closest_sph_primary_pairs(SmemFetch<PairP>{reinterpret_cast<const PairP *>(p.sph2_p)},
+                                (p.n_sph + 1) >> 1, p.n_tri, dir[0], hit[0]);
     } else {
       closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p}, p.n_sph, p.n_tri, dv, hit);
     }
@@ -874,6 +1076,9 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
             anyhit_sph_pk(SmemFetch<Sph2>{reinterpret_cast<const Sph2 *>(p.sph)}, n4, p.n_tri,
                           ov[0], Lv[0], a);
             anyhit_sph<V, NV>(SmemFetch<DevSph>{p.sph + n4}, p.n_sph - n4, p.n_tri + n4, ov, Lv, a);
+          } else if constexpr (PX == 1) {
+            anyhit_sph_pairs(SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2)},
+                             (p.n_sph + 1) >> 1, p.n_tri, ro[0], rL[0], a[0]);
           } else {
             anyhit_sph<V, NV>(SmemFetch<DevSph>{p.sph}, p.n_sph, p.n_tri, ov, Lv, a);
           }
@@ -1064,11 +1269,12 @@ extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t ran
 // host-side launchers (called from rt_capi.cpp)
 // ---------------------------------------------------------------------------------------
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
-                                  esc::DevSphP *sph_p, hipStream_t stream) {
+                                  esc::DevSphP *sph_p, esc::DevSphPairP *sph2_p,
+                                  hipStream_t stream) {
   const int n = p->n_tri > p->n_sph ? p->n_tri : p->n_sph;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
-                     tri_p, p->n_tri, p->sph, sph_p, p->n_sph, p->origin[0], p->origin[1],
+                     tri_p, p->n_tri, p->sph, sph_p, sph2_p, p->n_sph, p->origin[0], p->origin[1],
                      p->origin[2]);
   return (int)hipGetLastError();
 }
@@ -1081,7 +1287,9 @@ static int launch_render_variant(const esc::RenderParams *p, hipStream_t stream)
   const int tiles_y = (rows + esc::kTileH - 1) / esc::kTileH;
   const int n_tiles = tiles_x * tiles_y;
   const int grid = ((n_tiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((esc::k_render<STAGE, V, NV>), dim3(grid), dim3(256), 0, stream, *p);
+  // developer knob: unused dynamic LDS to cap workgroups per CU (occupancy sensitivity runs)
+  static const int lds_pad = getenv("ESC_DBG_LDS_PAD") ? atoi(getenv("ESC_DBG_LDS_PAD")) : 0;
+  hipLaunchKernelGGL((esc::k_render<STAGE, V, NV>), dim3(grid), dim3(256), lds_pad, stream, *p);
   return (int)hipGetLastError();
 }
 

@@ -236,3 +236,28 @@ def test_viewer_cli_surface():
     assert r.returncode != 0 and "Invalid Argument: --bogus" in r.stderr
     r = subprocess.run([exe, "-v", "1,2"], capture_output=True, text=True)
     assert r.returncode != 0 and "Error parsing view" in r.stderr
+
+
+def test_host_code_under_sanitizers(tmp_path, golden_dir):
+    """scene model, loader, synthetic scenes, flatten and PPM writer under ASan + UBSan (CPU
+    build of the host half only; the GPU pool offers no sanitizer runs)"""
+    exe = tmp_path / "host_sanitize"
+    src = [os.path.join(ROOT, "tools", "host_sanitize.cpp")] + [
+        os.path.join(ROOT, "esctp1raytracer_amd", "host", f)
+        for f in ("host_core.cpp", "obj_loader.cpp", "synth.cpp")]
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                        "-fno-omit-frame-pointer", "-ffp-contract=off",
+                        "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "esctp1raytracer_amd", "host")] + src +
+                       ["-o", str(exe)], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert b.returncode == 0, b.stderr[-2000:]
+    objs = [os.path.join(golden_dir, "scenes", n) for n in ("one.obj", "two.obj")]
+    if os.path.isdir("/root/reference/src/models/cornell"):
+        objs += sorted(os.path.join("/root/reference/src/models/cornell", f)
+                       for f in os.listdir("/root/reference/src/models/cornell") if f.endswith(".obj"))
+    r = subprocess.run([str(exe)] + objs, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "failures=0" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr
+    assert "runtime error" not in r.stderr

@@ -1,0 +1,18 @@
+"""Render a few frames of one kernel variant (for rocprofv3 --pmc runs)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import esctp1raytracer_amd as esc
+px = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+stage = {"smem": esc.ESC_STAGE_SMEM, "lds": esc.ESC_STAGE_LDS}[sys.argv[2] if len(sys.argv) > 2 else "smem"]
+shadows = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
+cfg = sys.argv[4] if len(sys.argv) > 4 else "c4"
+W, H = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (3840, 2160)
+r = esc.Renderer(0)
+r.upload(esc.Scene.synthetic(cfg))
+cam = esc.Camera.for_image(*esc.synthetic_view(), W, H)
+buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
+for _ in range(3):
+    r.render_rows(cam, W, H, 0, H, out_f32=buf, stage=stage, shadows=shadows, px=px)
+r.synchronize()
+print(r.counters())
