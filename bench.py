@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--stage", default="auto", choices=["auto", "smem", "lds"])
     ap.add_argument("--gather", default="f32", choices=["f32", "u8"],
                     help="what rank 0 collects: fp32 RGB (the seam's return_image) or PPM bytes")
-    ap.add_argument("--cpu-rows", type=int, default=128,
+    ap.add_argument("--cpu-rows", type=int, default=768,
                     help="rows of the frame the CPU baseline renders (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo lets several ranks share one GPU to rehearse the N>1 path")
