@@ -163,6 +163,58 @@ int run_asm(const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
   return 0;
 }
 
+// MODE 6/7: does a v_pk op with two VGPR-pair sources pay for VGPR bank conflicts?  16 independent
+// v_pk_mul_f32 per block with explicit registers: sources in the SAME banks (v[8:9] x v[12:13],
+// both pairs start at bank 0) versus in DIFFERENT banks (v[8:9] x v[14:15]).
+template <int CONFLICT>
+__global__ void __launch_bounds__(256) kbank(int n, float *out) {
+  float acc = 0.f;
+  for (int k = 0; k < n; ++k) {
+    if (CONFLICT) {
+      asm volatile(
+          "v_pk_mul_f32 v[16:17], v[8:9], v[12:13]\n\tv_pk_mul_f32 v[20:21], v[8:9], v[12:13]\n\t"
+          "v_pk_mul_f32 v[24:25], v[8:9], v[12:13]\n\tv_pk_mul_f32 v[28:29], v[8:9], v[12:13]\n\t"
+          "v_pk_mul_f32 v[32:33], v[8:9], v[12:13]\n\tv_pk_mul_f32 v[36:37], v[8:9], v[12:13]\n\t"
+          "v_pk_mul_f32 v[40:41], v[8:9], v[12:13]\n\tv_pk_mul_f32 v[44:45], v[8:9], v[12:13]\n\t"
+          "v_pk_mul_f32 v[16:17], v[8:9], v[12:13]\n\tv_pk_mul_f32 v[20:21], v[8:9], v[12:13]\n\t"
+          "v_pk_mul_f32 v[24:25], v[8:9], v[12:13]\n\tv_pk_mul_f32 v[28:29], v[8:9], v[12:13]\n\t"
+          "v_pk_mul_f32 v[32:33], v[8:9], v[12:13]\n\tv_pk_mul_f32 v[36:37], v[8:9], v[12:13]\n\t"
+          "v_pk_mul_f32 v[40:41], v[8:9], v[12:13]\n\tv_pk_mul_f32 v[44:45], v[8:9], v[12:13]\n\t"
+          ::: "v8","v9","v12","v13","v14","v15","v16","v17","v20","v21","v24","v25","v28","v29","v32","v33","v36","v37","v40","v41","v44","v45");
+    } else {
+      asm volatile(
+          "v_pk_mul_f32 v[16:17], v[8:9], v[14:15]\n\tv_pk_mul_f32 v[20:21], v[8:9], v[14:15]\n\t"
+          "v_pk_mul_f32 v[24:25], v[8:9], v[14:15]\n\tv_pk_mul_f32 v[28:29], v[8:9], v[14:15]\n\t"
+          "v_pk_mul_f32 v[32:33], v[8:9], v[14:15]\n\tv_pk_mul_f32 v[36:37], v[8:9], v[14:15]\n\t"
+          "v_pk_mul_f32 v[40:41], v[8:9], v[14:15]\n\tv_pk_mul_f32 v[44:45], v[8:9], v[14:15]\n\t"
+          "v_pk_mul_f32 v[16:17], v[8:9], v[14:15]\n\tv_pk_mul_f32 v[20:21], v[8:9], v[14:15]\n\t"
+          "v_pk_mul_f32 v[24:25], v[8:9], v[14:15]\n\tv_pk_mul_f32 v[28:29], v[8:9], v[14:15]\n\t"
+          "v_pk_mul_f32 v[32:33], v[8:9], v[14:15]\n\tv_pk_mul_f32 v[36:37], v[8:9], v[14:15]\n\t"
+          "v_pk_mul_f32 v[40:41], v[8:9], v[14:15]\n\tv_pk_mul_f32 v[44:45], v[8:9], v[14:15]\n\t"
+          ::: "v8","v9","v12","v13","v14","v15","v16","v17","v20","v21","v24","v25","v28","v29","v32","v33","v36","v37","v40","v41","v44","v45");
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int CONFLICT> int run_bank(float *d_out, int blocks) {
+  const int n = 20000;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kbank<CONFLICT>, dim3(blocks), dim3(256), 0, 0, 16, d_out);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kbank<CONFLICT>, dim3(blocks), dim3(256), 0, 0, n, d_out);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double wave_instr = (double)blocks * 4 * n * 16;
+  double per = wave_instr / 1024.0 / (ms * 1e3);
+  printf("mode%d v_pk src banks %-9s blocks %6d  %8.3f ms  -> %.2f cycles/pk-instr @2.4GHz\n", 6 + CONFLICT,
+         CONFLICT ? "same" : "different", blocks, ms, 2400.0 / per);
+  return 0;
+}
+
 template <int MODE> int run(const char *name, int valu_per_4, const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -190,7 +242,7 @@ int main() {
   CHECK(hipMalloc((void **)&d_tab, n * sizeof(float4)));
   CHECK(hipMalloc((void **)&d_out, 4));
   CHECK(hipMemcpy(d_tab, h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  for (int blocks : {1024, 2048, 16384}) {
+  for (int blocks : {2048, 8192}) {
     int iters = 16384 * 8 / blocks; if (iters < 1) iters = 1; if (iters > 64) iters = 64;
     if (run<0>("mode0 vgpr mul/add x32", 32, d_tab, d_out, n, iters, blocks)) return 1;
     if (run<1>("mode1 sphere body smem", 32, d_tab, d_out, n, iters, blocks)) return 1;
@@ -198,6 +250,8 @@ int main() {
     if (run<3>("mode3 +filter/branch lds", 31, d_tab, d_out, n, iters, blocks)) return 1;
     if (run_pk(d_out, n, iters, blocks)) return 1;
     if (run_asm(d_tab, d_out, n, iters, blocks)) return 1;
+    if (run_bank<0>(d_out, blocks)) return 1;
+    if (run_bank<1>(d_out, blocks)) return 1;
   }
   return 0;
 }
