@@ -31,6 +31,8 @@
 namespace esc {
 
 #define DEVINL __device__ __forceinline__
+// wave-uniform, rarely true: keeps the exact tails out of the hot loops' instruction stream
+#define ANY_LANE_RARE(cond) __builtin_expect(__builtin_amdgcn_ballot_w64(cond) != 0, 0)
 
 constexpr int STAGE_SMEM = 1;
 constexpr int STAGE_LDS = 2;
@@ -241,7 +243,7 @@ DEVINL void test_tri2_primary(const DevTriP (&T)[2], int idx, const V3<V> (&d)[N
       for (int c = 0; c < LN; ++c)
         any |= tri_candidate(comp(det[j][i], c), comp(un[j][i], c), comp(vn[j][i], c));
     }
-  if (__builtin_amdgcn_ballot_w64(any)) { // wave-uniform skip of the f64 tail
+  if (ANY_LANE_RARE(any)) { // wave-uniform skip of the f64 tail
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -444,7 +446,11 @@ DEVINL void pair2_primary_pk(const PairP (&R)[2], v2f dxy, v2f dz_, v2f (&b)[2],
 // q = b*b - cc, for records R0 (spheres 0,1) and R1 (spheres 2,3)
 DEVINL void pair2_any_pk(const PairG (&R)[2], v2f oxy, v2f oz_, v2f Lxy, v2f Lz_, v2f (&b)[2],
                          v2f (&q)[2]) {
-  v2f ax, ay, az, bx, by, bz, t0, t1;
+  // Scheduling rule measured in tools/ubench/valu_rate.hip (modes 8/10): a v_pk result must not
+  // be consumed within the next 3 instructions of the same wave (other waves do not fill the
+  // gap): 227 -> 148 cycles per block.  Four chains are kept in flight: dot(oc,L) and dot(oc,oc)
+  // of record 0 and of record 1.
+  v2f ax, ay, az, bx, by, bz, t0, t1, u0, u1;
   asm("v_pk_add_f32 %[ax], %[oxy], %[r0x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %[bx], %[oxy], %[r1x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %[ay], %[oxy], %[r0y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -453,34 +459,35 @@ DEVINL void pair2_any_pk(const PairG (&R)[2], v2f oxy, v2f oz_, v2f Lxy, v2f Lz_
       "v_pk_add_f32 %[bz], %[oz], %[r1z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_mul_f32 %[b0], %[ax], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
       "v_pk_mul_f32 %[b1], %[bx], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t0], %[ay], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %[t1], %[by], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
-      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
-      "v_pk_mul_f32 %[t0], %[az], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t1], %[bz], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
-      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
       "v_pk_mul_f32 %[q0], %[ax], %[ax]\n\t"
       "v_pk_mul_f32 %[q1], %[bx], %[bx]\n\t"
-      "v_pk_mul_f32 %[t0], %[ay], %[ay]\n\t"
-      "v_pk_mul_f32 %[t1], %[by], %[by]\n\t"
-      "v_pk_add_f32 %[q0], %[q0], %[t0]\n\t"
-      "v_pk_add_f32 %[q1], %[q1], %[t1]\n\t"
-      "v_pk_mul_f32 %[t0], %[az], %[az]\n\t"
-      "v_pk_mul_f32 %[t1], %[bz], %[bz]\n\t"
-      "v_pk_add_f32 %[q0], %[q0], %[t0]\n\t"
-      "v_pk_add_f32 %[q1], %[q1], %[t1]\n\t"
-      "v_pk_add_f32 %[q0], %[q0], %[r0r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[q1], %[q1], %[r1r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[u0], %[ay], %[ay]\n\t"
+      "v_pk_mul_f32 %[u1], %[by], %[by]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[u0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[u1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[u0], %[az], %[az]\n\t"
+      "v_pk_mul_f32 %[u1], %[bz], %[bz]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[u0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[u1]\n\t"
       "v_pk_mul_f32 %[t0], %[b0], %[b0]\n\t"
       "v_pk_mul_f32 %[t1], %[b1], %[b1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[r0r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[r1r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 1\n\t"
       "v_pk_add_f32 %[q0], %[t0], %[q0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %[q1], %[t1], %[q1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "s_nop 0"
       : [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [q0] "=&v"(q[0]), [q1] "=&v"(q[1]), [ax] "=&v"(ax),
         [ay] "=&v"(ay), [az] "=&v"(az), [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz),
-        [t0] "=&v"(t0), [t1] "=&v"(t1)
+        [t0] "=&v"(t0), [t1] "=&v"(t1), [u0] "=&v"(u0), [u1] "=&v"(u1)
       : [oxy] "v"(oxy), [oz] "v"(oz_), [Lxy] "v"(Lxy), [Lz] "v"(Lz_), [r0x] "s"(R[0].x),
         [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0r] "s"(R[0].r), [r1x] "s"(R[1].x),
         [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1r] "s"(R[1].r));
@@ -495,7 +502,7 @@ DEVINL void closest_sph_primary_pairs(Fetch rec, int n_rec, int base, f3 d, Hit 
     pair2_primary_pk(R, dxy, dz_, b, q);
     const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
                       __float_as_int(q[1].y));
-    if (__builtin_amdgcn_ballot_w64(m >= 0)) {
+    if (ANY_LANE_RARE(m >= 0)) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -550,7 +557,7 @@ DEVINL void test_sph_primary(const DevSphP (&s)[NB], int idx, const V3<V> (&d)[N
 #pragma unroll
       for (int c = 0; c < LN; ++c) m = fmaxf(m, comp(q[j][i], c));
     }
-  if (__builtin_amdgcn_ballot_w64(!(m < 0.f))) {
+  if (ANY_LANE_RARE(!(m < 0.f))) {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -593,7 +600,7 @@ DEVINL void closest_sph_primary_pk(Fetch rec, int n, int base, const V3<v2f> &d,
   auto test4 = [&](const SphP2(&S)[4], int idx) {
     v2f b[4], q[4];
     sph4_primary_pk(S, d.x, d.y, d.z, b, q);
-    if (__builtin_amdgcn_ballot_w64(any_nonneg(q[0], q[1], q[2], q[3]))) {
+    if (ANY_LANE_RARE(any_nonneg(q[0], q[1], q[2], q[3]))) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -663,7 +670,7 @@ DEVINL void test_tri_any(const DevTri &T, int idx, const V3<V> (&o)[NV], const V
     for (int c = 0; c < LN; ++c)
       any |= tri_candidate(comp(det[j], c), comp(un[j], c), comp(vn[j], c));
   }
-  if (__builtin_amdgcn_ballot_w64(any)) {
+  if (ANY_LANE_RARE(any)) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const V tn = dotu(e2, qv[j]); // :45 numerator
@@ -720,7 +727,7 @@ DEVINL void test_sph_any(const DevSph (&s)[NB], int idx, const V3<V> (&o)[NV],
 #pragma unroll
       for (int c = 0; c < LN; ++c) m = fmaxf(m, comp(q[j][i], c));
     }
-  if (__builtin_amdgcn_ballot_w64(!(m < 0.f))) {
+  if (ANY_LANE_RARE(!(m < 0.f))) {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -774,7 +781,7 @@ DEVINL void anyhit_sph_pk(Fetch rec, int n, int base, const V3<v2f> &o, const V3
     sph2_any_pk(S, o.x, o.y, o.z, L.x, L.y, L.z, b, q);
     const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
                       __float_as_int(q[1].y));
-    if (__builtin_amdgcn_ballot_w64(m >= 0)) {
+    if (ANY_LANE_RARE(m >= 0)) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -823,26 +830,30 @@ DEVINL void anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a)
       }
     }
   };
-  auto test = [&](const PairG(&R)[2], int idx) {
-    v2f b[2], q[2];
-    pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
-    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
-                      __float_as_int(q[1].y));
-    if (__builtin_amdgcn_ballot_w64(m >= 0)) accept(b, q, idx, 2);
+  // 8 spheres (4 records) per iteration: two packed bodies, ONE candidate filter, one branch.
+  // No hand prefetch here: other waves cover the scalar-load latency, and a single register
+  // set leaves room for the 32 SGPRs the four records need.
+  auto test4 = [&](const PairG(&R0)[2], const PairG(&R1)[2], int idx) {
+    v2f b0[2], q0[2], b1[2], q1[2];
+    pair2_any_pk(R0, oxy, oz_, Lxy, Lz_, b0, q0);
+    pair2_any_pk(R1, oxy, oz_, Lxy, Lz_, b1, q1);
+    int m = max(max3i(__float_as_int(q0[0].x), __float_as_int(q0[0].y), __float_as_int(q0[1].x)),
+                __float_as_int(q0[1].y));
+    m = max3i(m, __float_as_int(q1[0].x), __float_as_int(q1[0].y));
+    m = max3i(m, __float_as_int(q1[1].x), __float_as_int(q1[1].y));
+    if (ANY_LANE_RARE(m >= 0)) {
+      accept(b0, q0, idx, 2);
+      accept(b1, q1, idx + 4, 2);
+    }
   };
   for (int k0 = 0; k0 < n_rec; k0 += kPairExitRecords) {
     if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return;
     const int m = min(kPairExitRecords, n_rec - k0);
     const int m4 = m & ~3;
-    if (m4) {
-      PairG A[2], B[2];
-      fetch_batch(rec, k0, A);
-      for (int k = 0; k < m4; k += 4) {
-        fetch_batch(rec, rec.landed(A[1].r, k0 + k + 2), B);
-        test(A, base + 2 * (k0 + k));
-        fetch_batch(rec, rec.landed(B[1].r, k0 + min(k + 4, m - 2)), A);
-        test(B, base + 2 * (k0 + k + 2));
-      }
+    for (int k = 0; k < m4; k += 4) {
+      const PairG R0[2] = {rec(k0 + k), rec(k0 + k + 1)};
+      const PairG R1[2] = {rec(k0 + k + 2), rec(k0 + k + 3)};
+      test4(R0, R1, base + 2 * (k0 + k));
     }
     for (int k = m4; k < m; ++k) {
       const PairG R[2] = {rec(k0 + k), rec(k0 + k)};
@@ -916,16 +927,16 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
   __shared__ float lds_px[TW * kTileH * 3];
 
-  // ---- workgroup -> pixel tile.  Blocks are dealt round-robin over the 8 XCDs, so block b
-  // and b+8 share an L2; give each XCD one contiguous run of tiles (= contiguous framebuffer
-  // rows) instead of every 8th tile.  Grid is padded to a multiple of 8; surplus blocks exit.
+  // ---- workgroup -> pixel tile.  The dispatcher deals blocks round-robin over the 8 XCDs
+  // (block b runs on XCD b % 8), so with the identity map every XCD gets every 8th tile of
+  // every image row: an even mix of cheap (sky: primary rays only) and expensive (floor:
+  // primary + shadow) tiles.  That balance is what matters here -- tiles share no data beyond
+  // the scene tables, which every XCD's L2 holds anyway.  (Giving each XCD one contiguous run
+  // of tiles, the usual GEMM remap, was measured first: the XCDs that drew sky rows went idle
+  // and the frame took 23.6 ms instead of 19.x.)
   const int rows = p.n_local_rows;
   const int tiles_x = (p.W + TW - 1) / TW;
-  const int tiles_y = (rows + kTileH - 1) / kTileH;
-  const int n_tiles = tiles_x * tiles_y;
-  const int per_xcd = gridDim.x >> 3;
-  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (tile >= n_tiles) return; // whole workgroup leaves together (no barrier yet)
+  const int tile = blockIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
 
   const int tid = threadIdx.x;
@@ -1285,8 +1296,7 @@ static int launch_render_variant(const esc::RenderParams *p, hipStream_t stream)
   const int tw = 32 * NV * esc::lanes_of<V>::n;
   const int tiles_x = (p->W + tw - 1) / tw;
   const int tiles_y = (rows + esc::kTileH - 1) / esc::kTileH;
-  const int n_tiles = tiles_x * tiles_y;
-  const int grid = ((n_tiles + 7) / 8) * 8;
+  const int grid = tiles_x * tiles_y;
   // developer knob: unused dynamic LDS to cap workgroups per CU (occupancy sensitivity runs)
   static const int lds_pad = getenv("ESC_DBG_LDS_PAD") ? atoi(getenv("ESC_DBG_LDS_PAD")) : 0;
   hipLaunchKernelGGL((esc::k_render<STAGE, V, NV>), dim3(grid), dim3(256), lds_pad, stream, *p);

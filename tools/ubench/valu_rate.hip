@@ -166,6 +166,7 @@ int run_asm(const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
 // MODE 6/7: does a v_pk op with two VGPR-pair sources pay for VGPR bank conflicts?  16 independent
 // v_pk_mul_f32 per block with explicit registers: sources in the SAME banks (v[8:9] x v[12:13],
 // both pairs start at bank 0) versus in DIFFERENT banks (v[8:9] x v[14:15]).
+
 template <int CONFLICT>
 __global__ void __launch_bounds__(256) kbank(int n, float *out) {
   float acc = 0.f;
@@ -215,6 +216,307 @@ template <int CONFLICT> int run_bank(float *d_out, int blocks) {
   return 0;
 }
 
+// MODE 8: the kernel's shadow-ray pair body (32 v_pk per 4 spheres, 1 ray per lane) in isolation
+struct PairG { v2f x, y, z, r; };
+__device__ __forceinline__ void pair2_any_pk(const PairG (&R)[2], v2f oxy, v2f oz_, v2f Lxy, v2f Lz_, v2f (&b)[2],
+                         v2f (&q)[2]) {
+  // Scheduling rule measured in tools/ubench/valu_rate.hip (modes 8/10): a v_pk result must not
+  // be consumed within the next 3 instructions of the same wave (other waves do not fill the
+  // gap): 227 -> 148 cycles per block.  Four chains are kept in flight: dot(oc,L) and dot(oc,oc)
+  // of record 0 and of record 1.
+  v2f ax, ay, az, bx, by, bz, t0, t1, u0, u1;
+  asm("v_pk_add_f32 %[ax], %[oxy], %[r0x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bx], %[oxy], %[r1x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay], %[oxy], %[r0y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[by], %[oxy], %[r1y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az], %[oz], %[r0z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bz], %[oz], %[r1z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[b0], %[ax], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b1], %[bx], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[q0], %[ax], %[ax]\n\t"
+      "v_pk_mul_f32 %[q1], %[bx], %[bx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[u0], %[ay], %[ay]\n\t"
+      "v_pk_mul_f32 %[u1], %[by], %[by]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[u0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[u1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[u0], %[az], %[az]\n\t"
+      "v_pk_mul_f32 %[u1], %[bz], %[bz]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[u0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[u1]\n\t"
+      "v_pk_mul_f32 %[t0], %[b0], %[b0]\n\t"
+      "v_pk_mul_f32 %[t1], %[b1], %[b1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[r0r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[r1r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 1\n\t"
+      "v_pk_add_f32 %[q0], %[t0], %[q0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[t1], %[q1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [q0] "=&v"(q[0]), [q1] "=&v"(q[1]), [ax] "=&v"(ax),
+        [ay] "=&v"(ay), [az] "=&v"(az), [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz),
+        [t0] "=&v"(t0), [t1] "=&v"(t1), [u0] "=&v"(u0), [u1] "=&v"(u1)
+      : [oxy] "v"(oxy), [oz] "v"(oz_), [Lxy] "v"(Lxy), [Lz] "v"(Lz_), [r0x] "s"(R[0].x),
+        [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0r] "s"(R[0].r), [r1x] "s"(R[1].x),
+        [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1r] "s"(R[1].r));
+}
+
+__device__ __forceinline__ void pair2_any_pk_splat(const PairG (&R)[2], v2f ox2, v2f oy2, v2f oz2, v2f Lx2, v2f Ly2, v2f Lz2,
+                                                    v2f (&b)[2], v2f (&q)[2]) {
+  v2f ax, ay, az, bx, by, bz, t0, t1;
+  asm("v_pk_add_f32 %[ax], %[r0x], %[ox] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[bx], %[r1x], %[ox] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[ay], %[r0y], %[oy] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[by], %[r1y], %[oy] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[az], %[r0z], %[oz] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[bz], %[r1z], %[oz] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b0], %[ax], %[Lx]\n\t"
+      "v_pk_mul_f32 %[b1], %[bx], %[Lx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[Ly]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[Ly]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[Lz]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[Lz]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_mul_f32 %[q0], %[ax], %[ax]\n\t"
+      "v_pk_mul_f32 %[q1], %[bx], %[bx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[ay]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[by]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[t0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[az]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[bz]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[t0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[t1]\n\t"
+      "v_pk_add_f32 %[q0], %[r0r], %[q0] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[q1], %[r1r], %[q1] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t0], %[b0], %[b0]\n\t"
+      "v_pk_mul_f32 %[t1], %[b1], %[b1]\n\t"
+      "v_pk_add_f32 %[q0], %[t0], %[q0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[t1], %[q1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [q0] "=&v"(q[0]), [q1] "=&v"(q[1]), [ax] "=&v"(ax),
+        [ay] "=&v"(ay), [az] "=&v"(az), [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz),
+        [t0] "=&v"(t0), [t1] "=&v"(t1)
+      : [ox] "v"(ox2), [oy] "v"(oy2), [oz] "v"(oz2), [Lx] "v"(Lx2), [Ly] "v"(Ly2), [Lz] "v"(Lz2), [r0x] "s"(R[0].x),
+        [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0r] "s"(R[0].r), [r1x] "s"(R[1].x),
+        [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1r] "s"(R[1].r));
+}
+
+__device__ __forceinline__ void pairN_any_pk(const PairG (&R)[4], v2f oxy, v2f oz_, v2f Lxy, v2f Lz_, v2f (&b)[4], v2f (&q)[4]) {
+  v2f ax[4], ay[4], az[4], t[4];
+  asm("v_pk_add_f32 %[ax0], %[oxy], %[r0x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ax1], %[oxy], %[r1x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ax2], %[oxy], %[r2x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ax3], %[oxy], %[r3x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay0], %[oxy], %[r0y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay1], %[oxy], %[r1y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay2], %[oxy], %[r2y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay3], %[oxy], %[r3y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az0], %[oz], %[r0z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az1], %[oz], %[r1z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az2], %[oz], %[r2z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az3], %[oz], %[r3z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[b0], %[ax0], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b1], %[ax1], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b2], %[ax2], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b3], %[ax3], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay0], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t1], %[ay1], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t2], %[ay2], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t3], %[ay3], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_add_f32 %[b2], %[b2], %[t2]\n\t"
+      "v_pk_add_f32 %[b3], %[b3], %[t3]\n\t"
+      "v_pk_mul_f32 %[t0], %[az0], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[az1], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t2], %[az2], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t3], %[az3], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_add_f32 %[b2], %[b2], %[t2]\n\t"
+      "v_pk_add_f32 %[b3], %[b3], %[t3]\n\t"
+      "v_pk_mul_f32 %[q0], %[ax0], %[ax0]\n\t"
+      "v_pk_mul_f32 %[q1], %[ax1], %[ax1]\n\t"
+      "v_pk_mul_f32 %[q2], %[ax2], %[ax2]\n\t"
+      "v_pk_mul_f32 %[q3], %[ax3], %[ax3]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay0], %[ay0]\n\t"
+      "v_pk_mul_f32 %[t1], %[ay1], %[ay1]\n\t"
+      "v_pk_mul_f32 %[t2], %[ay2], %[ay2]\n\t"
+      "v_pk_mul_f32 %[t3], %[ay3], %[ay3]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[t0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[t1]\n\t"
+      "v_pk_add_f32 %[q2], %[q2], %[t2]\n\t"
+      "v_pk_add_f32 %[q3], %[q3], %[t3]\n\t"
+      "v_pk_mul_f32 %[t0], %[az0], %[az0]\n\t"
+      "v_pk_mul_f32 %[t1], %[az1], %[az1]\n\t"
+      "v_pk_mul_f32 %[t2], %[az2], %[az2]\n\t"
+      "v_pk_mul_f32 %[t3], %[az3], %[az3]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[t0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[t1]\n\t"
+      "v_pk_add_f32 %[q2], %[q2], %[t2]\n\t"
+      "v_pk_add_f32 %[q3], %[q3], %[t3]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[r0r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[r1r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q2], %[q2], %[r2r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q3], %[q3], %[r3r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[t0], %[b0], %[b0]\n\t"
+      "v_pk_mul_f32 %[t1], %[b1], %[b1]\n\t"
+      "v_pk_mul_f32 %[t2], %[b2], %[b2]\n\t"
+      "v_pk_mul_f32 %[t3], %[b3], %[b3]\n\t"
+      "v_pk_add_f32 %[q0], %[t0], %[q0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[t1], %[q1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q2], %[t2], %[q2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q3], %[t3], %[q3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [b0] "=&v"(b[0]), [q0] "=&v"(q[0]), [ax0] "=&v"(ax[0]), [ay0] "=&v"(ay[0]), [az0] "=&v"(az[0]), [t0] "=&v"(t[0]), [b1] "=&v"(b[1]), [q1] "=&v"(q[1]), [ax1] "=&v"(ax[1]), [ay1] "=&v"(ay[1]), [az1] "=&v"(az[1]), [t1] "=&v"(t[1]), [b2] "=&v"(b[2]), [q2] "=&v"(q[2]), [ax2] "=&v"(ax[2]), [ay2] "=&v"(ay[2]), [az2] "=&v"(az[2]), [t2] "=&v"(t[2]), [b3] "=&v"(b[3]), [q3] "=&v"(q[3]), [ax3] "=&v"(ax[3]), [ay3] "=&v"(ay[3]), [az3] "=&v"(az[3]), [t3] "=&v"(t[3])
+      : [oxy] "v"(oxy), [oz] "v"(oz_), [Lxy] "v"(Lxy), [Lz] "v"(Lz_), [r0x] "s"(R[0].x), [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0r] "s"(R[0].r), [r1x] "s"(R[1].x), [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1r] "s"(R[1].r), [r2x] "s"(R[2].x), [r2y] "s"(R[2].y), [r2z] "s"(R[2].z), [r2r] "s"(R[2].r), [r3x] "s"(R[3].x), [r3y] "s"(R[3].y), [r3z] "s"(R[3].z), [r3r] "s"(R[3].r));
+}
+
+__global__ void __launch_bounds__(256) kshadow4(const PairG *__restrict__ tab, int n_rec, int iters, float *out,
+                                                float ox, float oy, float oz) {
+  float acc = 0.f;
+  v2f oxy = {ox + threadIdx.x * 1e-6f, oy}, oz_ = {oz, 0.f}, Lxy = {0.6f, 0.0f}, Lz_ = {0.8f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    for (int k = 0; k + 4 <= n_rec; k += 4) {
+      const PairG R[4] = {tab[k], tab[k + 1], tab[k + 2], tab[k + 3]};
+      v2f b[4], q[4];
+      pairN_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+      int m = max(max(max(__float_as_int(q[0].x), __float_as_int(q[0].y)), __float_as_int(q[1].x)), __float_as_int(q[1].y));
+      m = max(m, max(max(max(__float_as_int(q[2].x), __float_as_int(q[2].y)), __float_as_int(q[3].x)), __float_as_int(q[3].y)));
+      if (__builtin_amdgcn_ballot_w64(m >= 0)) acc += sqrtf(q[0].x) + b[0].y + b[1].x + q[1].y + b[2].x + b[3].y + q[2].y + q[3].x;
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+int run_shadow4(const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const int n_rec = n / 2;
+  hipLaunchKernelGGL(kshadow4, dim3(blocks), dim3(256), 0, 0, (const PairG *)d_tab, n_rec, 1, d_out, 100.f, 200.f, 300.f);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kshadow4, dim3(blocks), dim3(256), 0, 0, (const PairG *)d_tab, n_rec, iters, d_out, 100.f, 200.f, 300.f);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double wave_blocks = (double)blocks * 4 * iters * (n_rec / 2);  // in 4-sphere units
+  double per = wave_blocks / 1024.0 / (ms * 1e-3);
+  printf("%-28s blocks %6d  %8.3f ms  -> %.1f cycles per 4-sphere unit @2.4GHz (8 spheres per asm, 4 chains)\n",
+         "mode10 shadow body 4 chains", blocks, ms, 2.4e9 / per);
+  return 0;
+}
+
+// MODE 11: two 2-record bodies per loop iteration (8 spheres per fetch / filter / branch)
+__global__ void __launch_bounds__(256) kshadow2x(const PairG *__restrict__ tab, int n_rec, int iters, float *out,
+                                                 float ox, float oy, float oz) {
+  float acc = 0.f;
+  v2f oxy = {ox + threadIdx.x * 1e-6f, oy}, oz_ = {oz, 0.f}, Lxy = {0.6f, 0.0f}, Lz_ = {0.8f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    for (int k = 0; k + 4 <= n_rec; k += 4) {
+      const PairG R0[2] = {tab[k], tab[k + 1]};
+      const PairG R1[2] = {tab[k + 2], tab[k + 3]};
+      v2f b0[2], q0[2], b1[2], q1[2];
+      pair2_any_pk(R0, oxy, oz_, Lxy, Lz_, b0, q0);
+      pair2_any_pk(R1, oxy, oz_, Lxy, Lz_, b1, q1);
+      int m = max(max(max(__float_as_int(q0[0].x), __float_as_int(q0[0].y)), __float_as_int(q0[1].x)), __float_as_int(q0[1].y));
+      m = max(m, max(max(max(__float_as_int(q1[0].x), __float_as_int(q1[0].y)), __float_as_int(q1[1].x)), __float_as_int(q1[1].y)));
+      if (__builtin_amdgcn_ballot_w64(m >= 0)) acc += sqrtf(q0[0].x) + b0[0].y + b0[1].x + q0[1].y + b1[0].x + b1[1].y + q1[0].y + q1[1].x;
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+// MODE 12: same, but each wave starts its sweep at its own offset, so co-resident waves do not
+// find each other's lines in the scalar cache (what happens in k_render, where waves drift apart)
+__global__ void __launch_bounds__(256) kshadow2x_off(const PairG *__restrict__ tab, int n_rec, int iters, float *out,
+                                                 float ox, float oy, float oz) {
+  float acc = 0.f;
+  v2f oxy = {ox + threadIdx.x * 1e-6f, oy}, oz_ = {oz, 0.f}, Lxy = {0.6f, 0.0f}, Lz_ = {0.8f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int off = __builtin_amdgcn_readfirstlane((int)((wave_id * 2654435761u) % (unsigned)(n_rec / 4)) * 4);
+    for (int kk = 0; kk + 4 <= n_rec; kk += 4) {
+      int k = kk + off; if (k >= n_rec - 3) k -= (n_rec & ~3);
+      const PairG R0[2] = {tab[k], tab[k + 1]};
+      const PairG R1[2] = {tab[k + 2], tab[k + 3]};
+      v2f b0[2], q0[2], b1[2], q1[2];
+      pair2_any_pk(R0, oxy, oz_, Lxy, Lz_, b0, q0);
+      pair2_any_pk(R1, oxy, oz_, Lxy, Lz_, b1, q1);
+      int m = max(max(max(__float_as_int(q0[0].x), __float_as_int(q0[0].y)), __float_as_int(q0[1].x)), __float_as_int(q0[1].y));
+      m = max(m, max(max(max(__float_as_int(q1[0].x), __float_as_int(q1[0].y)), __float_as_int(q1[1].x)), __float_as_int(q1[1].y)));
+      if (__builtin_amdgcn_ballot_w64(m >= 0)) acc += sqrtf(q0[0].x) + b0[0].y + b0[1].x + q0[1].y + b1[0].x + b1[1].y + q1[0].y + q1[1].x;
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int OFF> int run_shadow2x(const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
+  auto kern = OFF ? kshadow2x_off : kshadow2x;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const int n_rec = n / 2;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, (const PairG *)d_tab, n_rec, 1, d_out, 100.f, 200.f, 300.f);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, (const PairG *)d_tab, n_rec, iters, d_out, 100.f, 200.f, 300.f);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double wave_blocks = (double)blocks * 4 * iters * (n_rec / 2);
+  double per = wave_blocks / 1024.0 / (ms * 1e-3);
+  printf("%-28s blocks %6d  %8.3f ms  -> %.1f cycles per 4-sphere unit @2.4GHz (two 2-record bodies per iteration)\n",
+         OFF ? "mode12 +per-wave offsets" : "mode11 shadow 2x body/iter", blocks, ms, 2.4e9 / per);
+  return 0;
+}
+
+
+template <int VARIANT>
+__global__ void __launch_bounds__(256) kshadow(const PairG *__restrict__ tab, int n_rec, int iters, float *out,
+                                               float ox, float oy, float oz) {
+  float acc = 0.f;
+  v2f oxy = {ox + threadIdx.x * 1e-6f, oy}, oz_ = {oz, 0.f}, Lxy = {0.6f, 0.0f}, Lz_ = {0.8f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    for (int k = 0; k + 2 <= n_rec; k += 2) {
+      const PairG R[2] = {tab[k], tab[k + 1]};
+      v2f b[2], q[2];
+      if (VARIANT == 0) pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+      else pair2_any_pk_splat(R, (v2f){oxy.x, oxy.x}, (v2f){oxy.y, oxy.y}, (v2f){oz_.x, oz_.x}, (v2f){Lxy.x, Lxy.x}, (v2f){Lxy.y, Lxy.y}, (v2f){Lz_.x, Lz_.x}, b, q);
+      const int m = max(max(max(__float_as_int(q[0].x), __float_as_int(q[0].y)), __float_as_int(q[1].x)), __float_as_int(q[1].y));
+      if (__builtin_amdgcn_ballot_w64(m >= 0)) acc += sqrtf(q[0].x) + b[0].y + b[1].x + q[1].y;
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int VARIANT> int run_shadow(const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const int n_rec = n / 2;
+  hipLaunchKernelGGL(kshadow<VARIANT>, dim3(blocks), dim3(256), 0, 0, (const PairG *)d_tab, n_rec, 1, d_out, 100.f, 200.f, 300.f);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kshadow<VARIANT>, dim3(blocks), dim3(256), 0, 0, (const PairG *)d_tab, n_rec, iters, d_out, 100.f, 200.f, 300.f);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double wave_blocks = (double)blocks * 4 * iters * (n_rec / 2);
+  double per = wave_blocks / 1024.0 / (ms * 1e-3);   // blocks per SIMD per second
+  printf("%-28s blocks %6d  %8.3f ms  -> %.1f cycles per 4-sphere block @2.4GHz (model 32*4.1+3*2.7 = 139)\n",
+         VARIANT ? "mode9 shadow body, splat regs" : "mode8 shadow pair body smem", blocks, ms, 2.4e9 / per);
+  return 0;
+}
+
 template <int MODE> int run(const char *name, int valu_per_4, const float4 *d_tab, float *d_out, int n, int iters, int blocks) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -250,6 +552,11 @@ int main() {
     if (run<3>("mode3 +filter/branch lds", 31, d_tab, d_out, n, iters, blocks)) return 1;
     if (run_pk(d_out, n, iters, blocks)) return 1;
     if (run_asm(d_tab, d_out, n, iters, blocks)) return 1;
+    if (run_shadow<0>(d_tab, d_out, n, iters, blocks)) return 1;
+    if (run_shadow<1>(d_tab, d_out, n, iters, blocks)) return 1;
+    if (run_shadow4(d_tab, d_out, n, iters, blocks)) return 1;
+    if (run_shadow2x<0>(d_tab, d_out, n, iters, blocks)) return 1;
+    if (run_shadow2x<1>(d_tab, d_out, n, iters, blocks)) return 1;
     if (run_bank<0>(d_out, blocks)) return 1;
     if (run_bank<1>(d_out, blocks)) return 1;
   }
