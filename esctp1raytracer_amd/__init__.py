@@ -177,8 +177,7 @@ def synthetic_view():
 
 def _options(shadows, face_mode, fixed_face, seed, stage, px=0):
     o = _capi.esc_render_options()
-    o.pixels_per_lane = px % 100
-    o.reserved = px // 100  # developer experiments (kernel variants); 0 in normal use
+    o.pixels_per_lane = px
     o.shadows = 1 if shadows else 0
     o.face_mode = face_mode
     o.fixed_face = fixed_face
@@ -300,7 +299,8 @@ class Renderer:
         c = _capi.esc_counters()
         check(self._lib.esc_read_counters(self._h, C.byref(c)))
         return {"primary_rays": c.primary_rays, "hit_pixels": c.hit_pixels,
-                "shadow_rays": c.shadow_rays, "anyhit_tests": c.anyhit_tests}
+                "shadow_rays": c.shadow_rays, "anyhit_tests": c.anyhit_tests,
+                "anyhit_lane_tests": c.anyhit_lane_tests}
 
 
 def strip_local_rows(H, strip_rows, first_strip, strip_stride):

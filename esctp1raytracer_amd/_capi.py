@@ -68,7 +68,8 @@ class esc_render_options(C.Structure):
 
 class esc_counters(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("hit_pixels", C.c_uint64),
-                ("shadow_rays", C.c_uint64), ("anyhit_tests", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("anyhit_tests", C.c_uint64),
+                ("anyhit_lane_tests", C.c_uint64)]
 
 
 _P = C.c_void_p

@@ -55,6 +55,8 @@ struct esc_context {
   bool have_scene = false;
   bool prepared = false;
   float prepared_origin[3] = {0, 0, 0};
+  esc::HitRec *d_hits = nullptr; // k_primary -> k_shade hand-over
+  size_t hits_cap = 0;
   // scratch framebuffers for esc_render_frame_host
   float *d_img = nullptr;
   uint8_t *d_u8 = nullptr;
@@ -302,8 +304,8 @@ int esc_context_create(int32_t device, esc_context **out) {
     return ESC_ERR_HIP;
   }
   ctx->own_stream = true;
-  hipError_t ce = hipMalloc((void **)&ctx->d_counters, 8 * sizeof(unsigned long long));
-  if (ce == hipSuccess) ce = hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long));
+  hipError_t ce = hipMalloc((void **)&ctx->d_counters, esc::kCounterSets * 8 * sizeof(unsigned long long));
+  if (ce == hipSuccess) ce = hipMemset(ctx->d_counters, 0, esc::kCounterSets * 8 * sizeof(unsigned long long));
   if (ce != hipSuccess) {
     set_error(std::string("hipMalloc(counters): ") + hipGetErrorString(ce));
     esc_context_destroy(ctx);
@@ -320,7 +322,7 @@ void esc_context_destroy(esc_context *ctx) {
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
                   ctx->d_sph2,   ctx->d_sph2_p,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
-                  ctx->d_counters, ctx->d_img,  ctx->d_u8};
+                  ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -439,10 +441,22 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.face_mode = opts->face_mode;
   p.fixed_face = opts->fixed_face;
   p.seed = opts->seed;
-  p.pad0 = opts->reserved;
   p.out_f32 = d_rgb_f32;
   p.out_u8 = d_rgb_u8;
   p.counters = ctx->d_counters;
+  {
+    const size_t need = (size_t)n_local_rows * W;
+    if (ctx->hits_cap < need) {
+      // grow-only scratch; the stream is idle-synchronised so an earlier frame cannot still use it
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (ctx->d_hits) HIP_TRY(hipFree(ctx->d_hits));
+      ctx->d_hits = nullptr;
+      ctx->hits_cap = 0;
+      HIP_TRY(hipMalloc((void **)&ctx->d_hits, need * sizeof(esc::HitRec)));
+      ctx->hits_cap = need;
+    }
+    p.hits = ctx->d_hits;
+  }
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
     int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_sph_p, ctx->d_sph2_p, ctx->stream);
@@ -454,9 +468,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     ctx->prepared = true;
   }
   const int stage = (opts->stage == ESC_STAGE_LDS) ? 2 : 1; // AUTO -> SMEM (measured)
-  // AUTO: measured on the c4 workload: 1 pixel per lane when shadow rays
-  // are traced, 2 (packed fp32) for primary-only frames
-  const int px = opts->pixels_per_lane ? opts->pixels_per_lane : (opts->shadows ? 1 : 2);
+  // pixels per work-item of the PRIMARY pass; AUTO = 2 (measured)
+  const int px = opts->pixels_per_lane ? opts->pixels_per_lane : 2;
   int e = esc_launch_render(&p, stage, px, ctx->stream);
   if (e) {
     set_error(std::string("k_render launch: ") + hipGetErrorString((hipError_t)e));
@@ -541,7 +554,7 @@ int esc_reset_counters(esc_context *ctx) {
     return ESC_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, esc::kCounterSets * 8 * sizeof(unsigned long long), ctx->stream));
   return ESC_OK;
 }
 
@@ -551,13 +564,17 @@ int esc_read_counters(esc_context *ctx, esc_counters *out) {
     return ESC_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  unsigned long long h[4];
-  HIP_TRY(hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long all[esc::kCounterSets * 8];
+  HIP_TRY(hipMemcpyAsync(all, ctx->d_counters, sizeof(all), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  unsigned long long h[5] = {0, 0, 0, 0, 0};
+  for (int s = 0; s < esc::kCounterSets; s++)
+    for (int j = 0; j < 5; j++) h[j] += all[s * 8 + j];
   out->primary_rays = h[0];
   out->hit_pixels = h[1];
   out->shadow_rays = h[2];
   out->anyhit_tests = h[3];
+  out->anyhit_lane_tests = h[4];
   return ESC_OK;
 }
 

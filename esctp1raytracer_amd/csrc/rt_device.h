@@ -79,6 +79,14 @@ struct DevLight {
   int32_t n_faces;
 };
 
+// hand-over between k_primary and k_shade: closest hit of one pixel (main.cpp:715-722 state)
+struct alignas(16) HitRec {
+  float t;     // FLT_MAX when nothing was hit
+  float v;     // quirk S1: only v survives
+  int32_t idx; // -1 none; [0,n_tri) triangle; n_tri + k sphere k
+  int32_t pad;
+};
+
 struct RenderParams {
   // camera.h:36-39
   float origin[3];
@@ -104,12 +112,15 @@ struct RenderParams {
   uint64_t seed;
   float *out_f32;   // band-local, may be null
   uint8_t *out_u8;  // band-local, may be null
-  unsigned long long *counters; // [4] primary, hit, shadow rays, any-hit tests
+  // kCounterSets replicas of {primary, hit, shadow rays, any-hit tests, 4 spare}, 64 B each
+  unsigned long long *counters;
+  HitRec *hits;                 // band-local, n_local_rows * W records (scratch owned by the context)
 };
 
 // pixel tile of one 256-thread workgroup: 2 x 2 waves, each wave (16*PX) x 4 pixels, so the
 // tile is (32*PX) x 8 with PX = pixels per lane
 constexpr int kTileH = 8;
+constexpr int kCounterSets = 64; // replicas of the ray counters (contention), summed on read
 constexpr int kLdsChunkBytes = 32768; // LDS staging chunk (ESC_STAGE_LDS)
 
 } // namespace esc

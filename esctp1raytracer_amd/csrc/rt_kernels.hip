@@ -813,7 +813,8 @@ DEVINL void anyhit_sph_pk(Fetch rec, int n, int base, const V3<v2f> &o, const V3
 // any-hit over pair records (1 pixel per lane, two spheres per packed op)
 constexpr int kPairExitRecords = 128; // exit check every 256 spheres (it drains the fetch pipeline)
 template <typename Fetch>
-DEVINL void anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a) {
+DEVINL int anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a) {
+  int swept = 0; // pair records this wave actually tested (wave-uniform)
   const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
   auto accept = [&](const v2f(&b)[2], const v2f(&q)[2], int idx, int nrec) {
 #pragma unroll
@@ -847,8 +848,9 @@ DEVINL void anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a)
     }
   };
   for (int k0 = 0; k0 < n_rec; k0 += kPairExitRecords) {
-    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return;
+    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return swept;
     const int m = min(kPairExitRecords, n_rec - k0);
+    swept += m;
     const int m4 = m & ~3;
     for (int k = 0; k < m4; k += 4) {
       const PairG R0[2] = {rec(k0 + k), rec(k0 + k + 1)};
@@ -862,6 +864,7 @@ DEVINL void anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a)
       accept(b, q, base + 2 * (k0 + k), 1);
     }
   }
+  return swept;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -872,7 +875,21 @@ DEVINL void anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a)
 // and the VALU takes the values straight from SGPRs.
 template <typename Rec> struct SmemFetch {
   const Rec *__restrict__ p;
-  DEVINL Rec operator()(int k) const { return p[k]; }
+  // Read through the CONSTANT address space: with a wave-uniform address hipcc then always
+  // selects s_load, also behind barriers / fences, where its "is this global memory ever
+  // written in the kernel?" analysis gives up and would fall back to per-lane global_load.
+  // The tables are written before the launch and never by k_render.
+  DEVINL Rec operator()(int k) const {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef const u4 __attribute__((address_space(4))) *ConstPtr;
+    static_assert(sizeof(Rec) % 16 == 0, "records are whole 16-byte pieces");
+    const ConstPtr src = (ConstPtr)(uintptr_t)(p + k);
+    Rec r;
+    u4 *dst = reinterpret_cast<u4 *>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Rec) / 16); ++i) dst[i] = src[i];
+    return r;
+  }
   // Scalar loads return out of order, so the only wait hipcc can emit is lgkmcnt(0).  Naming
   // one SGPR of the previous batch in an empty asm makes that wait land HERE, before the next
   // batch's s_load is issued, instead of behind it.
@@ -917,59 +934,118 @@ DEVINL uint32_t face_hash(uint64_t seed, uint32_t pixel, uint32_t light, uint32_
 }
 
 // ---------------------------------------------------------------------------------------
-// the frame kernel.  256 threads = 4 waves; a wave covers a (16*PX) x 4 pixel block, the
-// workgroup a (32*PX) x 8 tile (2 x 2 waves).
+// re-packing of undecided shadow rays inside a workgroup
+//
+// A wave runs an any-hit loop until its LAST ray is decided, so rays that found their occluder
+// early keep occupying lanes: on c4 only 66 % of the executed lane-tests belong to rays the
+// reference would still be testing.  The primitive list is therefore cut into segments; between
+// segments the workgroup's 256 rays are re-packed through LDS so that the still-undecided ones
+// fill whole waves (wave w takes rays [64w, 64w+64) of the packed list) and the other waves sit
+// the segment out.  Every ray still meets the primitives in index order and stops at its first
+// accepted one, so kocc / tocc -- and the image -- are unchanged.
 // ---------------------------------------------------------------------------------------
-template <int STAGE, typename V, int NV>
-__global__ void __launch_bounds__(256) k_render(const RenderParams p) {
-  constexpr int PX = NV * lanes_of<V>::n; // pixels per work-item
-  constexpr int TW = 32 * PX;             // tile width
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
-  __shared__ float lds_px[TW * kTileH * 3];
+struct RepackLds {
+  float ox[256], oy[256], oz[256]; // shadow-ray origin (main.cpp:757 `hit`)
+  float lx[256], ly[256], lz[256]; // unit direction
+  float tb[256];                   // bound; 0 = decided or never looking
+  float tocc[256];
+  int32_t kocc[256];
+  uint16_t list[256]; // packed position -> owning thread
+  int32_t wave_cnt[4];
+};
+constexpr int kSegTris = 256;     // primitives per segment between re-packs
+constexpr int kSegSphPairs = 512; // = 1024 spheres
 
-  // ---- workgroup -> pixel tile.  The dispatcher deals blocks round-robin over the 8 XCDs
-  // (block b runs on XCD b % 8), so with the identity map every XCD gets every 8th tile of
-  // every image row: an even mix of cheap (sky: primary rays only) and expensive (floor:
-  // primary + shadow) tiles.  That balance is what matters here -- tiles share no data beyond
-  // the scene tables, which every XCD's L2 holds anyway.  (Giving each XCD one contiguous run
-  // of tiles, the usual GEMM remap, was measured first: the XCDs that drew sky rows went idle
-  // and the frame took 23.6 ms instead of 19.x.)
-  const int rows = p.n_local_rows;
-  const int tiles_x = (p.W + TW - 1) / TW;
-  const int tile = blockIdx.x;
-  const int tx = tile % tiles_x, ty = tile / tiles_x;
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  int lx0 = (wave & 1) * (16 * PX) + (lane & 15); // pixel q of this lane: lx0 + 16 q
-  int ly = ((wave >> 1) << 2) + (lane >> 4);
-  if (PX == 1 && p.pad0 == 1) { // experiment: 8x8 wave footprint, waves side by side
-    lx0 = wave * 8 + (lane & 7);
-    ly = lane >> 3;
+// all 256 threads; returns the number of rays still looking (workgroup-uniform)
+DEVINL int repack_rays(RepackLds &R, int tid) {
+  __syncthreads(); // tb / kocc writes of the previous segment
+  const bool looking = R.tb[tid] > 0.f;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(looking);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (lane == 0) R.wave_cnt[wave] = __popcll(m);
+  __syncthreads();
+  int off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int c = R.wave_cnt[w];
+    off += (w < wave) ? c : 0;
+    total += c;
   }
-  const int w0 = tx * TW;
-  // local row lr (ascending h) -> image row h.  A contiguous band has strip_rows >= its
-  // height, so lr / strip_rows == 0 and h = h0 + lr; cyclic strips (multi-GPU) jump by
-  // strip_step image rows per strip.  strip_rows is a multiple of kTileH (host-checked).
-  const int lr0 = ty * kTileH;
-  const int h_tile = p.h0 + (lr0 / p.strip_rows) * p.strip_step + (lr0 % p.strip_rows);
-  const int lr = lr0 + ly;
-  const int h = h_tile + ly;
-  const bool row_ok = (lr < rows) && (h < p.H);
+  if (looking) R.list[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(total);
+}
 
-  // ---- main.cpp:709-713 + camera.h:31-34
+// ---------------------------------------------------------------------------------------
+// The frame = two kernels on the same stream.
+//
+//   k_primary<STAGE, V, NV>  camera.h:31-34 get_ray + main.cpp:722 closest hit over every
+//                            primitive; writes one 16-byte hit record per pixel.
+//   k_shade<STAGE>           main.cpp:723-789: normal, per-light shadow ray (occlusion()) and
+//                            Phong; fp32 RGB and/or the PPM-quantised bytes.
+//
+// One fused kernel was the first design (and is what "one work-item per pixel" suggests); it was
+// split because the two halves want different things: the primary pass is fastest with 2 pixels
+// per lane (every primitive fetch feeds 128 rays), the shadow pass with 1 (a wave retires as
+// soon as its 64 rays are decided) plus re-packing, and fused they held so many values live
+// across the hot loops that hipcc spilled SGPRs inside them.  The hand-over costs 133 MB of
+// writes + reads per 4K frame (~0.05 ms) and one kernel boundary (~1.5 us).
+//
+// 256 threads = 4 waves; a wave covers (16*PX) x 4 pixels, a workgroup a (32*PX) x 8 tile.
+// ---------------------------------------------------------------------------------------
+
+// workgroup -> pixel tile.  The dispatcher deals blocks round-robin over the 8 XCDs (block b
+// runs on XCD b % 8), so with the identity map every XCD gets every 8th tile of every image
+// row: an even mix of cheap (sky: primary rays only) and expensive (floor: primary + shadow)
+// tiles.  That balance is what matters here -- tiles share no data beyond the scene tables,
+// which every XCD's L2 holds anyway.  (Giving each XCD one contiguous run of tiles, the usual
+// GEMM remap, was measured first: the XCDs that drew sky rows went idle and the c4 frame took
+// 23.6 ms instead of 18.3.)
+template <int PX> struct Tile {
+  int w0, lr0, h_tile; // first column, first local row, image row of local row lr0
+  int lx0, ly;         // this lane: pixel q sits at column w0 + lx0 + 16 q, local row lr0 + ly
+  int wave, lane;
+  DEVINL Tile(const RenderParams &p) {
+    constexpr int TW = 32 * PX;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tid = threadIdx.x;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    lane = tid & 63;
+    lx0 = (wave & 1) * (16 * PX) + (lane & 15);
+    ly = ((wave >> 1) << 2) + (lane >> 4);
+    w0 = tx * TW;
+    // local row lr (ascending h) -> image row h.  A contiguous band has strip_rows >= its
+    // height, so lr / strip_rows == 0 and h = h0 + lr; cyclic strips (multi-GPU) jump by
+    // strip_step image rows per strip.  strip_rows is a multiple of kTileH (host-checked).
+    lr0 = ty * kTileH;
+    h_tile = p.h0 + (lr0 / p.strip_rows) * p.strip_step + (lr0 % p.strip_rows);
+  }
+};
+
+// main.cpp:709-713 + camera.h:31-34
+DEVINL f3 primary_dir(const RenderParams &p, int w, int h) {
   const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
+  const float is = (float)w / (float)(p.W - 1);
   const float it = (float)h / (float)(p.H - 1);
+  return normalize(((ld3(p.llc) + ld3(p.horizontal) * is) + ld3(p.vertical) * it) - origin);
+}
+
+template <int STAGE, typename V, int NV>
+__global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
+  constexpr int PX = NV * lanes_of<V>::n; // pixels per work-item
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
+  const Tile<PX> T(p);
+  const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly;
+  const bool row_ok = (lr < p.n_local_rows) && (h < p.H);
+
   int w[PX];
-  bool inside[PX];
   f3 dir[PX];
   Hit hit[PX];
 #pragma unroll
   for (int q = 0; q < PX; ++q) {
-    w[q] = w0 + lx0 + 16 * q;
-    inside[q] = row_ok && (w[q] < p.W);
-    const float is = (float)w[q] / (float)(p.W - 1);
-    dir[q] = normalize(((ld3(p.llc) + ld3(p.horizontal) * is) + ld3(p.vertical) * it) - origin);
+    w[q] = T.w0 + T.lx0 + 16 * q;
+    dir[q] = primary_dir(p, w[q], h);
     hit[q].t = FLT_MAX; // main.cpp:715
     hit[q].v = 0.f;
     hit[q].idx = -1;
@@ -1014,87 +1090,159 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
     }
   }
 
-  // ---- main.cpp:723-738 normal of the hit (per-lane gathers, once per pixel)
-  bool has_hit[PX];
-  f3 N[PX];
-  int mi[PX];
-  float t[PX], r[PX], g[PX], b[PX];
+  // ---- hand-over: t, v, idx per pixel (band-local pixel order), 16-byte stores
 #pragma unroll
-  for (int q = 0; q < PX; ++q) {
-    has_hit[q] = inside[q] && (hit[q].idx >= 0);
-    N[q] = mk(0.f, 0.f, 0.f);
-    mi[q] = 0;
-    t[q] = hit[q].t;
-    r[q] = g[q] = b[q] = 0.f; // vec3 default ctor, main.cpp:557-558
-    if (has_hit[q]) {
-      if (hit[q].idx < p.n_tri) {
-        const DevTri T = p.tri[hit[q].idx];
-        N[q] = normalize(cross(ld3(T.e1), ld3(T.e2))); // :728-731
-        mi[q] = T.geom;
-        if (p.mat[mi[q]].has_normals) { // :733-738 with u == 0 (quirk S1)
-          const DevTriN Q = p.tri_n[hit[q].idx];
-          const float u = 0.f, v = hit[q].v;
-          N[q] = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
-        }
-      } else {
-        const int k = hit[q].idx - p.n_tri;
-        const DevSph S = p.sph[k];
-        N[q] = normalize((origin + dir[q] * hit[q].t) - mk(S.cx, S.cy, S.cz)); // extension
-        mi[q] = p.sph_mat[k];
+  for (int q = 0; q < PX; ++q)
+    if (row_ok && w[q] < p.W) {
+      HitRec r;
+      r.t = hit[q].t;
+      r.v = hit[q].v;
+      r.idx = hit[q].idx;
+      r.pad = 0;
+      p.hits[(size_t)lr * p.W + w[q]] = r;
+    }
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(256, 6) k_shade(const RenderParams p) {
+  typedef float V;
+  constexpr int NV = 1;
+  constexpr int TW = 32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
+  __shared__ float lds_px[TW * kTileH * 3];
+  __shared__ RepackLds lds_rays; // SMEM stage only
+
+  const Tile<1> T(p);
+  const int tid = threadIdx.x;
+  const int wave = T.wave, lane = T.lane;
+  const int rows = p.n_local_rows;
+  const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly;
+  const int w = T.w0 + T.lx0;
+  const bool inside = (lr < rows) && (h < p.H) && (w < p.W);
+
+  const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
+  HitRec hr;
+  hr.t = FLT_MAX;
+  hr.v = 0.f;
+  hr.idx = -1;
+  hr.pad = 0;
+  if (inside) hr = p.hits[(size_t)lr * p.W + w];
+  const bool has_hit = inside && (hr.idx >= 0);
+
+  // ---- main.cpp:723-738 normal of the hit (per-lane gathers, once per pixel)
+  f3 N = mk(0.f, 0.f, 0.f);
+  int mi = 0;
+  if (has_hit) {
+    if (hr.idx < p.n_tri) {
+      const DevTri Tr = p.tri[hr.idx];
+      N = normalize(cross(ld3(Tr.e1), ld3(Tr.e2))); // :728-731
+      mi = Tr.geom;
+      if (p.mat[mi].has_normals) { // :733-738 with u == 0 (quirk S1)
+        const DevTriN Q = p.tri_n[hr.idx];
+        const float u = 0.f, v = hr.v;
+        N = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
       }
+    } else {
+      const int k = hr.idx - p.n_tri;
+      const DevSph S = p.sph[k];
+      const f3 dir = primary_dir(p, w, h);
+      N = normalize((origin + dir * hr.t) - mk(S.cx, S.cy, S.cz)); // extension
+      mi = p.sph_mat[k];
     }
   }
 
   // ---- main.cpp:740-789 per-light shading
+  float t = hr.t;
+  float r = 0.f, g = 0.f, b = 0.f; // vec3 default ctor, main.cpp:557-558
   const float nl = (float)p.n_lights;
   uint32_t n_shadow = 0;
   unsigned long long n_any = 0; // any-hit tests the reference would have executed
+  int n_swept = 0;              // primitives this WAVE swept in any-hit loops (x64 = lane-tests)
   for (int li = 0; li < p.n_lights; ++li) {
     const DevLight Lt = p.lights[li];
-    Any a[PX];
-    f3 ro[PX], rL[PX]; // shadow-ray origin (main.cpp:757 `hit`) and unit direction
-#pragma unroll
-    for (int q = 0; q < PX; ++q) {
-      ro[q] = N[q];
-      rL[q] = N[q];
-      a[q].tb = 0.f;
-      a[q].tocc = 0.f;
-      a[q].kocc = -1;
-      if (has_hit[q]) {
-        const uint32_t face =
-            (p.face_mode == 0) ? (uint32_t)p.fixed_face
-                               : face_hash(p.seed, (uint32_t)(h * p.W + w[q]), (uint32_t)li,
-                                           (uint32_t)Lt.n_faces);
-        const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
-        ro[q] = origin + dir[q] * (t[q] - FLT_EPSILON); // :757-758
-        rL[q] = P - ro[q];                              // :759
-        const float len = length(rL[q]);                // :761
-        t[q] = len - FLT_EPSILON;                       // :764
-        rL[q] = normalize(rL[q]);                       // :766
-        a[q].tb = t[q];
-      }
-      if (!(a[q].tb > 0.f)) a[q].tb = 0.f; // dead rays carry tb = 0
+    Any a[1];
+    f3 ro = N, rL = N; // shadow-ray origin (main.cpp:757 `hit`) and unit direction
+    a[0].tb = 0.f;
+    a[0].tocc = 0.f;
+    a[0].kocc = -1;
+    if (has_hit) {
+      const uint32_t face =
+          (p.face_mode == 0) ? (uint32_t)p.fixed_face
+                             : face_hash(p.seed, (uint32_t)(h * p.W + w), (uint32_t)li,
+                                         (uint32_t)Lt.n_faces);
+      const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
+      // the primary direction is recomputed here (same ops, same bits) rather than kept in
+      // registers across the any-hit loops of the previous light
+      const f3 dir = primary_dir(p, w, h);
+      ro = origin + dir * (t - FLT_EPSILON); // :757-758
+      rL = P - ro;                           // :759
+      const float len = length(rL);          // :761
+      t = len - FLT_EPSILON;                 // :764
+      rL = normalize(rL);                    // :766
+      a[0].tb = t;
     }
+    if (!(a[0].tb > 0.f)) a[0].tb = 0.f; // dead rays carry tb = 0
     if (p.shadows) { // :772 occlusion(): wave-uniform loops
-      V3<V> ov[NV], Lv[NV];
-      pack3<V, NV>(ro, ov);
-      pack3<V, NV>(rL, Lv);
-      if (STAGE == STAGE_SMEM) {
-        if (any_looking(a)) {
-          anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri}, p.n_tri, 0, ov, Lv, a);
-          if constexpr (PX == 2) {
-            const int n4 = p.n_sph & ~3;
-            anyhit_sph_pk(SmemFetch<Sph2>{reinterpret_cast<const Sph2 *>(p.sph)}, n4, p.n_tri,
-                          ov[0], Lv[0], a);
-            anyhit_sph<V, NV>(SmemFetch<DevSph>{p.sph + n4}, p.n_sph - n4, p.n_tri + n4, ov, Lv, a);
-          } else if constexpr (PX == 1) {
-            anyhit_sph_pairs(SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2)},
-                             (p.n_sph + 1) >> 1, p.n_tri, ro[0], rL[0], a[0]);
-          } else {
-            anyhit_sph<V, NV>(SmemFetch<DevSph>{p.sph}, p.n_sph, p.n_tri, ov, Lv, a);
+      if constexpr (STAGE == STAGE_SMEM) {
+        // ---- segments of the primitive list, undecided rays re-packed in between
+        RepackLds &R = lds_rays;
+        R.ox[tid] = ro.x; R.oy[tid] = ro.y; R.oz[tid] = ro.z;
+        R.lx[tid] = rL.x; R.ly[tid] = rL.y; R.lz[tid] = rL.z;
+        R.tb[tid] = a[0].tb;
+        R.kocc[tid] = -1;
+        R.tocc[tid] = 0.f;
+        // Occluded rays mostly meet their occluder early in the list, so re-packing pays at
+        // the beginning and not later: segment lengths double (256, 256, 512, 1024, ...
+        // triangles; 512, 512, 1024, ... pair records), which keeps the barriers few.
+        const int n_rec = (p.n_sph + 1) >> 1;
+        int k0 = 0, seg = kSegTris; // triangles first (index order)
+        bool in_tris = p.n_tri > 0;
+        if (!in_tris) seg = kSegSphPairs;
+        for (int sg = 0;; ++sg) {
+          if (in_tris && k0 >= p.n_tri) {
+            in_tris = false;
+            k0 = 0;
+            seg = kSegSphPairs;
+            sg = 0;
           }
+          if (!in_tris && k0 >= n_rec) break;
+          const int n_here = min(seg, (in_tris ? p.n_tri : n_rec) - k0);
+          const int n_live = repack_rays(R, tid);
+          if (n_live == 0) break; // workgroup-uniform
+          if (wave * 64 < n_live) { // otherwise this wave sits the segment out
+            const int slot = wave * 64 + lane;
+            const int rr = (slot < n_live) ? (int)R.list[slot] : -1;
+            const int rs = (rr >= 0) ? rr : tid;
+            Any aa[1];
+            aa[0].tb = (rr >= 0) ? R.tb[rs] : 0.f;
+            aa[0].tocc = 0.f;
+            aa[0].kocc = -1;
+            const f3 so = mk(R.ox[rs], R.oy[rs], R.oz[rs]);
+            const f3 sL = mk(R.lx[rs], R.ly[rs], R.lz[rs]);
+            if (in_tris) {
+              const V3<V> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
+              n_swept += n_here; // upper bound: exits inside a segment are not subtracted
+              anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri + k0}, n_here, k0, sov, sLv, aa);
+            } else {
+              n_swept += 2 * anyhit_sph_pairs(
+                                 SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + k0},
+                                 n_here, p.n_tri + 2 * k0, so, sL, aa[0]);
+            }
+            if (aa[0].kocc >= 0) { // rr >= 0 here: a dead lane has tb = 0 and accepts nothing
+              R.tb[rr] = 0.f;
+              R.tocc[rr] = aa[0].tocc;
+              R.kocc[rr] = aa[0].kocc;
+            }
+          }
+          k0 += n_here;
+          if (sg >= 1) seg *= 2;
         }
+        __syncthreads();
+        a[0].kocc = R.kocc[tid];
+        a[0].tocc = R.tocc[tid];
+        rL = mk(R.lx[tid], R.ly[tid], R.lz[tid]); // not kept live across the segments
       } else {
+        const V3<V> ov[1] = {{ro.x, ro.y, ro.z}}, Lv[1] = {{rL.x, rL.y, rL.z}};
         constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTri);
         for (int k0 = 0; k0 < p.n_tri; k0 += CT) {
           const int n = min(CT, p.n_tri - k0);
@@ -1115,39 +1263,39 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
         }
       }
     }
-#pragma unroll
-    for (int q = 0; q < PX; ++q) {
-      if (!has_hit[q]) continue;
+    if (has_hit) {
       if (p.shadows) {
         n_shadow += 1u;
         // tests occlusion() runs for this ray: up to and including its first occluder
-        n_any += (a[q].kocc >= 0) ? (unsigned)(a[q].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
+        n_any += (a[0].kocc >= 0) ? (unsigned)(a[0].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
       }
-      if (p.shadows && a[q].kocc >= 0) {
-        t[q] = a[q].tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
-        continue;         // :772-773
+      if (p.shadows && a[0].kocc >= 0) {
+        t = a[0].tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
+      } else {         // :772-773 `continue` otherwise
+        const float d = dot(N, rL); // :775
+        if (!(d <= 0.f)) {          // :777
+          const DevMat M = p.mat[mi];                  // :768
+          f3 c = (ld3(M.ka) * 0.5f + ld3(M.ke)) / nl; // :769-770
+          const f3 Hh = normalize((N + rL) * 2.f);     // :780
+          const float sp = powf(dot(N, Hh), M.Ns);
+          c = c + (ld3(M.kd) * d + ld3(M.ks) * sp) / nl; // :782-783
+          r += c.x;                                       // :786-788
+          g += c.y;
+          b += c.z;
+        }
       }
-      const float d = dot(N[q], rL[q]); // :775
-      if (d <= 0.f) continue;            // :777
-      const DevMat M = p.mat[mi[q]];     // :768
-      f3 c = (ld3(M.ka) * 0.5f + ld3(M.ke)) / nl; // :769-770
-      const f3 Hh = normalize((N[q] + rL[q]) * 2.f); // :780
-      const float sp = powf(dot(N[q], Hh), M.Ns);
-      c = c + (ld3(M.kd) * d + ld3(M.ks) * sp) / nl; // :782-783
-      r[q] += c.x;                                    // :786-788
-      g[q] += c.y;
-      b[q] += c.z;
     }
   }
 
-  // ---- counters: one atomic per wave (ballot + popcount)
+  // ---- counters: ballot + popcount per wave, summed per workgroup in LDS, then ONE global atomic
+  // per counter per workgroup into one of kCounterSets replicas (each on its own cache line).
+  // 130k waves adding to four words of one line took longer than shading itself (4.7 ms).
   if (p.counters) {
-    uint32_t ni = 0, nh = 0;
-#pragma unroll
-    for (int q = 0; q < PX; ++q) {
-      ni += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(inside[q]));
-      nh += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_hit[q]));
-    }
+    __shared__ unsigned long long wg_cnt[5];
+    if (tid < 5) wg_cnt[tid] = 0ull;
+    __syncthreads();
+    const uint32_t ni = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(inside));
+    const uint32_t nh = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_hit));
     uint32_t ns = n_shadow;
     unsigned long long na = n_any;
     for (int o = 32; o > 0; o >>= 1) {
@@ -1155,80 +1303,65 @@ __global__ void __launch_bounds__(256) k_render(const RenderParams p) {
       na += __shfl_down(na, o);
     }
     if (lane == 0) {
-      atomicAdd(&p.counters[0], (unsigned long long)ni);
-      atomicAdd(&p.counters[1], (unsigned long long)nh);
-      atomicAdd(&p.counters[2], (unsigned long long)ns);
-      if (na) atomicAdd(&p.counters[3], na);
+      atomicAdd(&wg_cnt[0], (unsigned long long)ni);
+      atomicAdd(&wg_cnt[1], (unsigned long long)nh);
+      atomicAdd(&wg_cnt[2], (unsigned long long)ns);
+      atomicAdd(&wg_cnt[3], na);
+      atomicAdd(&wg_cnt[4], (unsigned long long)n_swept * 64ull);
     }
+    __syncthreads();
+    if (tid < 5 && wg_cnt[tid])
+      atomicAdd(&p.counters[(blockIdx.x % kCounterSets) * 8 + tid], wg_cnt[tid]);
   }
 
   // ---- framebuffer: transpose the tile through LDS so each store instruction writes
   // consecutive dwords of one image row (12-byte pixels would otherwise stride the lanes).
-  const bool full_tile = (w0 + TW <= p.W) && (lr0 + kTileH <= rows) && (h_tile + kTileH <= p.H);
+  const int lx = T.lx0, ly = T.ly, w0 = T.w0, lr0 = T.lr0;
+  const bool full_tile = (w0 + TW <= p.W) && (lr0 + kTileH <= rows) && (T.h_tile + kTileH <= p.H);
   if (p.out_f32) {
     if (full_tile) {
-#pragma unroll
-      for (int q = 0; q < PX; ++q) {
-        const int li = (ly * TW + lx0 + 16 * q) * 3;
-        lds_px[li + 0] = r[q];
-        lds_px[li + 1] = g[q];
-        lds_px[li + 2] = b[q];
-      }
+      const int li = (ly * TW + lx) * 3;
+      lds_px[li + 0] = r;
+      lds_px[li + 1] = g;
+      lds_px[li + 2] = b;
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 3 * PX; ++i) {
-        const int idx = tid + 256 * i; // 0 .. TW*8*3-1
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i; // 0 .. 767
         const int row = idx / (TW * 3), col = idx % (TW * 3);
         const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + col;
         p.out_f32[o] = lds_px[idx];
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < PX; ++q)
-        if (inside[q]) {
-          const size_t o = ((size_t)lr * p.W + w[q]) * 3;
-          p.out_f32[o + 0] = r[q];
-          p.out_f32[o + 1] = g[q];
-          p.out_f32[o + 2] = b[q];
-        }
+    } else if (inside) {
+      const size_t o = ((size_t)lr * p.W + w) * 3;
+      p.out_f32[o + 0] = r;
+      p.out_f32[o + 1] = g;
+      p.out_f32[o + 2] = b;
     }
   }
   if (p.out_u8) { // main.cpp:676-682 clamp > 1, int(c * 255)
-    uint8_t qr[PX], qg[PX], qb[PX];
-#pragma unroll
-    for (int q = 0; q < PX; ++q) {
-      const float cr = (r[q] > 1.f) ? 1.f : r[q], cg = (g[q] > 1.f) ? 1.f : g[q],
-                  cb = (b[q] > 1.f) ? 1.f : b[q];
-      qr[q] = (uint8_t)(int)(cr * 255.f);
-      qg[q] = (uint8_t)(int)(cg * 255.f);
-      qb[q] = (uint8_t)(int)(cb * 255.f);
-    }
+    const float cr = (r > 1.f) ? 1.f : r, cg = (g > 1.f) ? 1.f : g, cb = (b > 1.f) ? 1.f : b;
+    const uint8_t qr = (uint8_t)(int)(cr * 255.f), qg = (uint8_t)(int)(cg * 255.f),
+                  qb = (uint8_t)(int)(cb * 255.f);
     if (full_tile && (p.W & 3) == 0) {
       __syncthreads(); // lds_px reuse
       unsigned char *lb = reinterpret_cast<unsigned char *>(lds_px);
-#pragma unroll
-      for (int q = 0; q < PX; ++q) {
-        const int li = (ly * TW + lx0 + 16 * q) * 3;
-        lb[li + 0] = qr[q];
-        lb[li + 1] = qg[q];
-        lb[li + 2] = qb[q];
-      }
+      const int li = (ly * TW + lx) * 3;
+      lb[li + 0] = qr;
+      lb[li + 1] = qg;
+      lb[li + 2] = qb;
       __syncthreads();
       constexpr int ROW_DW = TW * 3 / 4; // dwords per tile row
-      for (int i = tid; i < ROW_DW * kTileH; i += 256) {
-        const int row = i / ROW_DW, col = i % ROW_DW;
+      if (tid < ROW_DW * kTileH) {
+        const int row = tid / ROW_DW, col = tid % ROW_DW;
         const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + (size_t)col * 4;
-        *reinterpret_cast<uint32_t *>(p.out_u8 + o) = reinterpret_cast<const uint32_t *>(lb)[i];
+        *reinterpret_cast<uint32_t *>(p.out_u8 + o) = reinterpret_cast<const uint32_t *>(lb)[tid];
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < PX; ++q)
-        if (inside[q]) {
-          const size_t o = ((size_t)lr * p.W + w[q]) * 3;
-          p.out_u8[o + 0] = qr[q];
-          p.out_u8[o + 1] = qg[q];
-          p.out_u8[o + 2] = qb[q];
-        }
+    } else if (inside) {
+      const size_t o = ((size_t)lr * p.W + w) * 3;
+      p.out_u8[o + 0] = qr;
+      p.out_u8[o + 1] = qg;
+      p.out_u8[o + 2] = qb;
     }
   }
 }
@@ -1291,28 +1424,30 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
 }
 
 template <int STAGE, typename V, int NV>
-static int launch_render_variant(const esc::RenderParams *p, hipStream_t stream) {
-  const int rows = p->n_local_rows;
+static void launch_primary(const esc::RenderParams *p, hipStream_t stream) {
   const int tw = 32 * NV * esc::lanes_of<V>::n;
   const int tiles_x = (p->W + tw - 1) / tw;
-  const int tiles_y = (rows + esc::kTileH - 1) / esc::kTileH;
-  const int grid = tiles_x * tiles_y;
-  // developer knob: unused dynamic LDS to cap workgroups per CU (occupancy sensitivity runs)
-  static const int lds_pad = getenv("ESC_DBG_LDS_PAD") ? atoi(getenv("ESC_DBG_LDS_PAD")) : 0;
-  hipLaunchKernelGGL((esc::k_render<STAGE, V, NV>), dim3(grid), dim3(256), lds_pad, stream, *p);
-  return (int)hipGetLastError();
+  const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
+  hipLaunchKernelGGL((esc::k_primary<STAGE, V, NV>), dim3(tiles_x * tiles_y), dim3(256), 0, stream, *p);
 }
 
-// stage: 1 SMEM, 2 LDS.  px: pixels per lane (1, 2 or 4).
+// stage: 1 SMEM, 2 LDS.  px: pixels per work-item of the primary pass (1, 2 or 4); the shade
+// pass always carries one pixel per work-item.
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, hipStream_t stream) {
   if (p->n_local_rows <= 0 || p->W <= 0) return 0;
   using esc::v2f;
+  const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
+  const int shade_grid = ((p->W + 31) / 32) * tiles_y;
   if (stage == esc::STAGE_LDS) {
-    if (px == 1) return launch_render_variant<esc::STAGE_LDS, float, 1>(p, stream);
-    if (px == 2) return launch_render_variant<esc::STAGE_LDS, v2f, 1>(p, stream);
-    return launch_render_variant<esc::STAGE_LDS, v2f, 2>(p, stream);
+    if (px == 1) launch_primary<esc::STAGE_LDS, float, 1>(p, stream);
+    else if (px == 2) launch_primary<esc::STAGE_LDS, v2f, 1>(p, stream);
+    else launch_primary<esc::STAGE_LDS, v2f, 2>(p, stream);
+    hipLaunchKernelGGL((esc::k_shade<esc::STAGE_LDS>), dim3(shade_grid), dim3(256), 0, stream, *p);
+  } else {
+    if (px == 1) launch_primary<esc::STAGE_SMEM, float, 1>(p, stream);
+    else if (px == 2) launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream);
+    else launch_primary<esc::STAGE_SMEM, v2f, 2>(p, stream);
+    hipLaunchKernelGGL((esc::k_shade<esc::STAGE_SMEM>), dim3(shade_grid), dim3(256), 0, stream, *p);
   }
-  if (px == 1) return launch_render_variant<esc::STAGE_SMEM, float, 1>(p, stream);
-  if (px == 2) return launch_render_variant<esc::STAGE_SMEM, v2f, 1>(p, stream);
-  return launch_render_variant<esc::STAGE_SMEM, v2f, 2>(p, stream);
+  return (int)hipGetLastError();
 }

@@ -204,6 +204,10 @@ typedef struct {
   uint64_t shadow_rays;  /* occlusion() calls (main.cpp:772): hit pixels x lights */
   uint64_t anyhit_tests; /* primitive tests those calls execute in the reference: up to and
                             including the first occluder, else every primitive */
+  uint64_t anyhit_lane_tests; /* any-hit tests the GPU actually spent lanes on (64 per wave per
+                                 primitive swept, decided or idle lanes included); the ratio
+                                 anyhit_tests / anyhit_lane_tests is the lane efficiency of the
+                                 shadow pass (SMEM stage only, 0 otherwise) */
 } esc_counters;
 
 /* Creates a context on HIP device `device` with its own stream.  Fails with

@@ -176,7 +176,10 @@ def test_sphere_scenes_bit_exact(esc, renderer, config, n, shadows, stage, px):
                                return_counters=True)
     assert_bit_equal(gpu, ref, f"{config}/{n}/{stage}/px{px}")
     assert np.array_equal(u8, ol.oracle_quantise(ref))
+    lane_tests = cnt.pop("anyhit_lane_tests")
     assert cnt == rc
+    if shadows and stage == "smem":
+        assert lane_tests >= rc["anyhit_tests"]  # lanes spent >= tests the reference needs
     assert 0 < rc["hit_pixels"] < W * H
 
 

@@ -12,7 +12,11 @@ r = esc.Renderer(0)
 r.upload(esc.Scene.synthetic(cfg))
 cam = esc.Camera.for_image(*esc.synthetic_view(), W, H)
 buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
+r.reset_counters()
 for _ in range(3):
     r.render_rows(cam, W, H, 0, H, out_f32=buf, stage=stage, shadows=shadows, px=px)
 r.synchronize()
-print(r.counters())
+c = r.counters()
+print(c)
+if c['anyhit_lane_tests']:
+    print('shadow lane efficiency', c['anyhit_tests'] / c['anyhit_lane_tests'])

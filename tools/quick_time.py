@@ -19,7 +19,7 @@ eye, look = esc.synthetic_view()
 cam = esc.Camera.for_image(eye, look, W, H)
 buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
 variants = []
-for px in (1, 2):
+for px in (1, 2, 4):  # pixels per work-item of the primary pass
     variants += [(f"smem px{px}", esc.ESC_STAGE_SMEM, True, px), (f"lds px{px}", esc.ESC_STAGE_LDS, True, px),
                  (f"smem px{px} noshadow", esc.ESC_STAGE_SMEM, False, px),
                  (f"lds px{px} noshadow", esc.ESC_STAGE_LDS, False, px)]
