@@ -9,7 +9,7 @@ A "step" is one frame of the workload BASELINE.json's metric is quoted on (confi
 3840x2160, 10,000 random spheres + a 2-triangle floor + one single-triangle light, one primary
 ray per pixel and one shadow ray per hit pixel, brute force, scene resident in HBM.  With N
 ranks the frame is cut into 8-row strips dealt round-robin (esctp1raytracer_amd/multigpu.py),
-each rank renders its strips with k_render and the fp32 framebuffer is gathered to rank 0 over
+each rank renders its strips (k_primary + k_shade) and the fp32 framebuffer is gathered to rank 0 over
 RCCL and laid out as one frame there; total work is fixed, so scaling is "strong".
 
 Rank 0 prints ONE JSON line.  `value` = rays of all ranks / wall time (max over ranks) in
@@ -219,18 +219,18 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     c = torch.tensor([cnt["primary_rays"], cnt["shadow_rays"], cnt["anyhit_tests"],
-                      cnt["hit_pixels"]], dtype=torch.float64, device=dev)
+                      cnt["hit_pixels"], cnt["anyhit_lane_tests"]], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    primary, shadow, anyhit, hits = (float(x) for x in c.tolist())
+    primary, shadow, anyhit, hits, lane_tests = (float(x) for x in c.tolist())
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
 
     if rank == 0:
         rays = primary + shadow
         n_tri, n_sph = info["n_triangles"], info["n_spheres"]
-        # ---- roofline of the dominant kernel (k_render) on THIS rank's launch
+        # ---- roofline of the frame kernels (k_primary + k_shade) on THIS rank
         frame_bytes = my_rows * W * 3 * local[0].element_size()
         scene_bytes = n_sph * 32 + n_tri * 112 + (info["n_geometry"] + n_sph) * 64
         alg_bytes = frame_bytes + scene_bytes
@@ -277,8 +277,10 @@ def main():
                 "hit_pixels_per_frame": hits / a.steps,
                 "closest_hit_tests_per_frame": primary / a.steps * (n_tri + n_sph),
                 "anyhit_tests_per_frame": anyhit / a.steps,
+                "shadow_lane_efficiency": (anyhit / lane_tests) if lane_tests else None,
             },
-            "kernel": {"name": "k_render", "avg_ms": kernel_ms,
+            "kernel": {"name": "k_primary + k_shade (one frame = both, back to back on one stream)",
+                       "avg_ms": kernel_ms,
                        "launches_timed": len(events), "rank": 0, "rows": my_rows},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
