@@ -49,7 +49,11 @@ def parse():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--prims", type=int, default=0, help="override primitive count (0 = config's)")
-    ap.add_argument("--stage", default="auto", choices=["auto", "smem", "lds"])
+    ap.add_argument("--stage", default="auto", choices=["auto", "smem", "lds", "bvh"],
+                    help="auto/smem/lds are brute force (BASELINE's algorithm, the default); bvh "
+                         "makes the opt-in acceleration structure the measured path")
+    ap.add_argument("--no-accel", action="store_true",
+                    help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
     ap.add_argument("--gather", default="f32", choices=["f32", "u8"],
                     help="what rank 0 collects: fp32 RGB (the seam's return_image) or PPM bytes")
     ap.add_argument("--cpu-rows", type=int, default=768,
@@ -80,6 +84,44 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return max(1, min(n, 64))
+
+
+def accel_leg(esc, r, st, cam, eye, W, H, shadows, steps, warmup, brute_frame, alg_bytes):
+    """The same frame through ESC_STAGE_BVH (opt-in like the reference's --bvh):
+    tree build timed apart from the render (as main.cpp:569-579 does), K frames between HIP
+    events on the render stream, and EVERY fp32 value compared with the brute-force frame."""
+    acc = r.build_accel(eye)
+    buf = torch.zeros(H * W * 3, dtype=torch.float32, device=brute_frame.device)
+    ev = []
+    r.synchronize()
+    for i in range(warmup + steps):
+        if i == warmup:
+            r.synchronize()
+            r.reset_counters()
+        with torch.cuda.stream(st):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            r.render_rows(cam, W, H, 0, H, out_f32=buf, shadows=shadows, stage=esc.ESC_STAGE_BVH)
+            e1.record(st)
+        if i >= warmup:
+            ev.append((e0, e1))
+    st.synchronize()
+    cnt = r.counters()
+    ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    rays = (cnt["primary_rays"] + cnt["shadow_rays"]) / steps
+    differing = int((buf.view(torch.int32) != brute_frame[:H * W * 3].view(torch.int32)).sum().item())
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"stage": "bvh", "value": rays / (ms * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms,
+            "steps": steps, "timing": "HIP events around k_primary<BVH> + k_shade<BVH> per frame",
+            "fp32_values_differing_from_brute_force": differing,
+            "identical_to_brute_force": differing == 0,
+            "tree": {k: acc[k] for k in ("tri_nodes", "tri_depth", "sph_nodes", "sph_depth")},
+            "build_ms_host": acc["build_ms"],
+            "leaf_tests_per_shadow_ray": cnt["anyhit_tests"] / max(cnt["shadow_rays"], 1),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes}}
 
 
 def cpu_baseline(scene, eye, look, W, H, shadows, n_rows, gpu_frame):
@@ -135,7 +177,8 @@ def main():
     info = scene.info()
     eye, look = esc.synthetic_view()
     cam = esc.Camera.for_image(eye, look, W, H)
-    stage = {"auto": esc.ESC_STAGE_AUTO, "smem": esc.ESC_STAGE_SMEM, "lds": esc.ESC_STAGE_LDS}[a.stage]
+    stage = {"auto": esc.ESC_STAGE_AUTO, "smem": esc.ESC_STAGE_SMEM, "lds": esc.ESC_STAGE_LDS,
+             "bvh": esc.ESC_STAGE_BVH}[a.stage]
 
     st = torch.cuda.Stream(device=dev)
     r = esc.Renderer(local_rank, stream=st)
@@ -263,7 +306,7 @@ def main():
                 "workload": f"{a.config}: {W}x{H}, {n_sph} spheres + {n_tri} triangles, "
                             f"{info['n_lights']} light, 1 primary ray/pixel + "
                             f"{'1 shadow ray per hit pixel' if shadows else 'no shadow rays'}, "
-                            f"brute force",
+                            f"{'bounding-volume tree (opt-in)' if a.stage == 'bvh' else 'brute force'}",
                 "scene": "esc_scene_synthetic (SURVEY.md 8(d)): splitmix64 seeds 0xC2..0xC4",
                 "partition": f"{S}-row strips round-robin over {world} rank(s)",
                 "gather": ("none (1 GPU)" if world == 1 else
@@ -300,6 +343,9 @@ def main():
             out["cpu_baseline"] = cb
             out["gpu_vs_cpu"] = out["value"] / cb["value"]
             out["parity_sample_rows_bit_exact"] = same
+        if world == 1 and a.stage != "bvh" and not a.no_accel and not use_u8:
+            out["accel"] = accel_leg(esc, r, st, cam, eye, W, H, shadows, a.steps, a.warmup,
+                                     local[0], alg_bytes)
         if world > 1 and a.verify_rows > 0 and not use_u8:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import numpy as np

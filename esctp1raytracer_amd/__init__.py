@@ -12,12 +12,12 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_LDS,
+from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_BVH, ESC_STAGE_LDS,
                     ESC_STAGE_SMEM, EscError, check)
 
 __all__ = ["Scene", "Camera", "Renderer", "FlatScene", "render_multi", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
            "EscError", "ESC_FACE_FIXED", "ESC_FACE_HASH", "ESC_STAGE_AUTO", "ESC_STAGE_SMEM",
-           "ESC_STAGE_LDS", "version"]
+           "ESC_STAGE_LDS", "ESC_STAGE_BVH", "version"]
 
 
 def _f32(a, shape=None):
@@ -117,6 +117,35 @@ class Scene:
         if n:
             check(self._lib.esc_scene_spheres_copy(self._h, _fp(s), _fp(m)))
         return s, m
+
+    def build_accel(self, origin, which):
+        """Host-side build of the ESC_STAGE_BVH tree (no GPU needed): which = 'triangles' |
+        'spheres'.  Returns nodes (structured array), order (block slot -> primitive index, -1 =
+        pad), the padded primitive boxes (n, 2, 3) and the build summary."""
+        w = {"triangles": 0, "spheres": 1}[which]
+        o = _f32(origin, (3,))
+        info = _capi.esc_accel_info()
+        check(self._lib.esc_scene_build_accel(self._h, _fp(o), w, C.byref(info), None, 0, None, 0,
+                                              None, 0))
+        n_nodes = info.sph_nodes if w else info.tri_nodes
+        n_blocks = info.sph_blocks if w else info.tri_blocks
+        block = 4 if w else 2
+        n_prims = self.info()["n_spheres" if w else "n_triangles"]
+        node_dt = np.dtype([("lo0", np.float32, 3), ("hi0", np.float32, 3), ("lo1", np.float32, 3),
+                            ("hi1", np.float32, 3), ("child", np.int32, 2),
+                            ("minkey", np.uint32, 2)])
+        nodes = np.zeros(max(n_nodes, 1), node_dt)
+        order = np.full(max(n_blocks * block, 1), -1, np.int32)
+        boxes = np.zeros((max(n_prims, 1), 2, 3), np.float32)
+        check(self._lib.esc_scene_build_accel(
+            self._h, _fp(o), w, C.byref(info),
+            nodes.ctypes.data_as(C.POINTER(_capi.esc_bvh_node)), nodes.shape[0],
+            order.ctypes.data_as(C.POINTER(C.c_int32)), order.shape[0], _fp(boxes),
+            boxes.size))
+        return {"nodes": nodes[:n_nodes], "order": order[:n_blocks * block],
+                "boxes": boxes[:n_prims], "block": block,
+                "root": info.sph_root if w else info.tri_root,
+                "depth": info.sph_depth if w else info.tri_depth, "build_ms": info.build_ms}
 
     def flatten_ispc(self, sort_by_centroid_x=False):
         """flatten_scene_ispc (flatten_iscp.cpp:35-111) -> FlatScene."""
@@ -291,6 +320,20 @@ class Renderer:
             self._h, C.byref(camera.c), W, H, C.byref(o), _fp(img),
             u8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_u8 else None))
         return (img, u8) if want_u8 else img
+
+    def build_accel(self, origin):
+        """Build (or rebuild) the ESC_STAGE_BVH tree now instead of at the first frame that
+        asks for it."""
+        o = _f32(origin, (3,))
+        check(self._lib.esc_build_accel(self._h, _fp(o)))
+        return self.accel_info()
+
+    def accel_info(self):
+        i = _capi.esc_accel_info()
+        check(self._lib.esc_get_accel_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k in ("tri_nodes", "tri_blocks", "tri_depth", "tri_root",
+                                           "sph_nodes", "sph_blocks", "sph_depth", "sph_root",
+                                           "build_ms", "builds")}
 
     def reset_counters(self):
         check(self._lib.esc_reset_counters(self._h))

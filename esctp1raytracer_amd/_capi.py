@@ -23,6 +23,7 @@ ESC_FACE_HASH = 1
 ESC_STAGE_AUTO = 0
 ESC_STAGE_SMEM = 1
 ESC_STAGE_LDS = 2
+ESC_STAGE_BVH = 3
 ESC_MATERIAL_FLOATS = 13
 
 
@@ -72,6 +73,18 @@ class esc_counters(C.Structure):
                 ("anyhit_lane_tests", C.c_uint64)]
 
 
+class esc_bvh_node(C.Structure):  # 64 bytes
+    _fields_ = [("lo0", C.c_float * 3), ("hi0", C.c_float * 3), ("lo1", C.c_float * 3),
+                ("hi1", C.c_float * 3), ("child", C.c_int32 * 2), ("minkey", C.c_uint32 * 2)]
+
+
+class esc_accel_info(C.Structure):
+    _fields_ = [("tri_nodes", C.c_int32), ("tri_blocks", C.c_int32), ("tri_depth", C.c_int32),
+                ("tri_root", C.c_int32), ("sph_nodes", C.c_int32), ("sph_blocks", C.c_int32),
+                ("sph_depth", C.c_int32), ("sph_root", C.c_int32), ("build_ms", C.c_float),
+                ("builds", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
 _U8 = C.POINTER(C.c_uint8)
@@ -119,6 +132,11 @@ SIGNATURES = {
     "esc_strip_local_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "esc_assemble_strips": (C.c_int, [_P, _P, C.c_int32, C.c_size_t, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, _P]),
+    "esc_build_accel": (C.c_int, [_P, _F]),
+    "esc_get_accel_info": (C.c_int, [_P, C.POINTER(esc_accel_info)]),
+    "esc_scene_build_accel": (C.c_int, [_P, _F, C.c_int32, C.POINTER(esc_accel_info),
+                                        C.POINTER(esc_bvh_node), C.c_int64, _I32, C.c_int64, _F,
+                                        C.c_int64]),
     "esc_reset_counters": (C.c_int, [_P]),
     "esc_read_counters": (C.c_int, [_P, C.POINTER(esc_counters)]),
     "esc_render_frame_host": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32,

@@ -5,14 +5,19 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include "../host/accel_build.h"
 #include "../host/scene.h"
 #include "rt_device.h"
+
+static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNode) == 64,
+              "esc_bvh_node is the public face of esc::BvhNode");
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevSphP *sph_p, esc::DevSphPairP *sph2_p,
@@ -57,6 +62,17 @@ struct esc_context {
   float prepared_origin[3] = {0, 0, 0};
   esc::HitRec *d_hits = nullptr; // k_primary -> k_shade hand-over
   size_t hits_cap = 0;
+  // ESC_STAGE_BVH: host copy of the tables the builder reads, the tree in HBM
+  std::vector<esc::DevTri> h_tri;
+  std::vector<esc::DevSph> h_sph;
+  std::vector<float> h_light_points;
+  esc::BvhNode *d_bvh_tri_nodes = nullptr, *d_bvh_sph_nodes = nullptr;
+  esc::TriBlock *d_bvh_tri_blocks = nullptr;
+  esc::SphBlock *d_bvh_sph_blocks = nullptr;
+  int32_t *d_bvh_tri_order = nullptr, *d_bvh_sph_order = nullptr;
+  bool accel_valid = false;
+  esc::OriginBounds accel_ob{};
+  esc_accel_info accel_info{};
   // scratch framebuffers for esc_render_frame_host
   float *d_img = nullptr;
   uint8_t *d_u8 = nullptr;
@@ -269,6 +285,83 @@ int commit(esc_context *ctx, const Staged &s) {
   ctx->n_geom = s.n_geom;
   ctx->have_scene = true;
   ctx->prepared = false;
+  ctx->h_tri = s.tri;
+  ctx->h_sph = s.sph;
+  ctx->h_light_points = s.light_points;
+  ctx->accel_valid = false;
+  return ESC_OK;
+}
+
+// ---- acceleration structure: host build (accel_build.cpp) + leaf blocks in tree order
+struct AccelHost {
+  esc::BuiltBvh tri, sph;
+  std::vector<esc::TriBlock> tri_blocks;
+  std::vector<esc::SphBlock> sph_blocks;
+  std::vector<esc::PrimBox> tri_boxes, sph_boxes;
+  esc::OriginBounds ob;
+};
+
+void build_accel_host(const std::vector<esc::DevTri> &tri, const std::vector<esc::DevSph> &sph,
+                      const std::vector<float> &light_points, const float origin[3],
+                      AccelHost &a) {
+  a.ob = esc::origin_bounds(tri, sph, light_points, origin);
+  esc::triangle_boxes(tri, a.ob, a.tri_boxes);
+  esc::sphere_boxes(sph, a.ob, a.sph_boxes);
+  esc::build_bvh(a.tri_boxes, esc::kTriBlock, 0u, esc::kBvhMaxDepth, a.tri);
+  esc::build_bvh(a.sph_boxes, esc::kSphBlock, (uint32_t)tri.size(), esc::kBvhMaxDepth, a.sph);
+  a.tri_blocks.resize((size_t)a.tri.n_blocks);
+  for (size_t i = 0; i < a.tri.order.size(); i++) {
+    esc::DevTri &dst = a.tri_blocks[i / esc::kTriBlock].t[i % esc::kTriBlock];
+    if (a.tri.order[i] >= 0)
+      dst = tri[(size_t)a.tri.order[i]];
+    else
+      std::memset(&dst, 0, sizeof(dst)); // e1 = e2 = 0: det = 0, rejected at ray_triangle.h:23
+  }
+  a.sph_blocks.resize((size_t)a.sph.n_blocks);
+  for (size_t i = 0; i < a.sph.order.size(); i++) {
+    esc::DevSph &dst = a.sph_blocks[i / esc::kSphBlock].s[i % esc::kSphBlock];
+    if (a.sph.order[i] >= 0) {
+      dst = sph[(size_t)a.sph.order[i]];
+    } else { // disc = b*b - (|oc|^2 + inf) = -inf: never a hit
+      dst.cx = dst.cy = dst.cz = 0.f;
+      dst.r2 = -__builtin_huge_valf();
+    }
+  }
+}
+
+void fill_info(const AccelHost &a, esc_accel_info &info) {
+  info.tri_nodes = (int32_t)a.tri.nodes.size();
+  info.tri_blocks = a.tri.n_blocks;
+  info.tri_depth = a.tri.depth;
+  info.tri_root = a.tri.root;
+  info.sph_nodes = (int32_t)a.sph.nodes.size();
+  info.sph_blocks = a.sph.n_blocks;
+  info.sph_depth = a.sph.depth;
+  info.sph_root = a.sph.root;
+}
+
+int build_accel_device(esc_context *ctx, const float origin[3]) {
+  const auto t0 = std::chrono::steady_clock::now();
+  AccelHost a;
+  build_accel_host(ctx->h_tri, ctx->h_sph, ctx->h_light_points, origin, a);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream)); // no frame in flight may still walk the old tree
+  int rc;
+  if ((rc = upload_vec(ctx->d_bvh_tri_nodes, a.tri.nodes, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_bvh_tri_blocks, a.tri_blocks, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_bvh_tri_order, a.tri.order, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_bvh_sph_nodes, a.sph.nodes, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_bvh_sph_blocks, a.sph_blocks, ctx->stream))) return rc;
+  if ((rc = upload_vec(ctx->d_bvh_sph_order, a.sph.order, ctx->stream))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int builds = ctx->accel_info.builds;
+  std::memset(&ctx->accel_info, 0, sizeof(ctx->accel_info));
+  fill_info(a, ctx->accel_info);
+  ctx->accel_info.builds = builds + 1;
+  ctx->accel_info.build_ms =
+      std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->accel_ob = a.ob;
+  ctx->accel_valid = true;
   return ESC_OK;
 }
 
@@ -322,7 +415,9 @@ void esc_context_destroy(esc_context *ctx) {
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
                   ctx->d_sph2,   ctx->d_sph2_p,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
-                  ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits};
+                  ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits,
+                  ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
+                  ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_order};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -363,6 +458,62 @@ int esc_upload_scene(esc_context *ctx, const esc_scene *scene) {
   int rc = stage_scene(*scene, s);
   if (rc) return rc;
   return commit(ctx, s);
+}
+
+int esc_build_accel(esc_context *ctx, const float origin[3]) {
+  if (!ctx || !origin) {
+    set_error("esc_build_accel: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (!ctx->have_scene) {
+    set_error("esc_build_accel: no scene uploaded");
+    return ESC_ERR_INVALID;
+  }
+  return build_accel_device(ctx, origin);
+}
+
+int esc_get_accel_info(esc_context *ctx, esc_accel_info *out) {
+  if (!ctx || !out) {
+    set_error("esc_get_accel_info: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  *out = ctx->accel_info;
+  return ESC_OK;
+}
+
+int esc_scene_build_accel(const esc_scene *scene, const float origin[3], int32_t which,
+                          esc_accel_info *info, esc_bvh_node *nodes, int64_t nodes_cap,
+                          int32_t *order, int64_t order_cap, float *prim_boxes,
+                          int64_t prim_boxes_cap) {
+  if (!scene || !origin || (which != 0 && which != 1)) {
+    set_error("esc_scene_build_accel: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  Staged s;
+  int rc = stage_scene(*scene, s);
+  if (rc) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  AccelHost a;
+  build_accel_host(s.tri, s.sph, s.light_points, origin, a);
+  const esc::BuiltBvh &b = which ? a.sph : a.tri;
+  const std::vector<esc::PrimBox> &boxes = which ? a.sph_boxes : a.tri_boxes;
+  if ((nodes && nodes_cap < (int64_t)b.nodes.size()) ||
+      (order && order_cap < (int64_t)b.order.size()) ||
+      (prim_boxes && prim_boxes_cap < (int64_t)boxes.size() * 6)) {
+    set_error("esc_scene_build_accel: output buffer too small");
+    return ESC_ERR_INVALID;
+  }
+  if (nodes && !b.nodes.empty()) std::memcpy(nodes, b.nodes.data(), b.nodes.size() * sizeof(esc::BvhNode));
+  if (order && !b.order.empty()) std::memcpy(order, b.order.data(), b.order.size() * sizeof(int32_t));
+  if (prim_boxes && !boxes.empty()) std::memcpy(prim_boxes, boxes.data(), boxes.size() * sizeof(esc::PrimBox));
+  if (info) {
+    std::memset(info, 0, sizeof(*info));
+    fill_info(a, *info);
+    info->builds = 1;
+    info->build_ms =
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return ESC_OK;
 }
 
 int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle *triangles,
@@ -467,9 +618,21 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     std::memcpy(ctx->prepared_origin, cam->origin, 12);
     ctx->prepared = true;
   }
-  const int stage = (opts->stage == ESC_STAGE_LDS) ? 2 : 1; // AUTO -> SMEM (measured)
+  int stage = (opts->stage == ESC_STAGE_LDS) ? 2 : 1; // AUTO -> SMEM (measured)
   // pixels per work-item of the PRIMARY pass; AUTO = 2 (measured)
-  const int px = opts->pixels_per_lane ? opts->pixels_per_lane : 2;
+  int px = opts->pixels_per_lane ? opts->pixels_per_lane : 2;
+  if (opts->stage == ESC_STAGE_BVH) {
+    if (!ctx->accel_valid || !ctx->accel_ob.contains(cam->origin)) {
+      int rc = build_accel_device(ctx, cam->origin);
+      if (rc) return rc;
+    }
+    p.bvh_tri = esc::BvhRef{ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
+                            ctx->accel_info.tri_root, 0};
+    p.bvh_sph = esc::BvhRef{ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_order,
+                            ctx->accel_info.sph_root, 0};
+    stage = 3;
+    px = 1; // a wave walks the tree with its 64 rays
+  }
   int e = esc_launch_render(&p, stage, px, ctx->stream);
   if (e) {
     set_error(std::string("k_render launch: ") + hipGetErrorString((hipError_t)e));

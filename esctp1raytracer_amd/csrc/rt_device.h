@@ -87,6 +87,40 @@ struct alignas(16) HitRec {
   int32_t pad;
 };
 
+// ---------------------------------------------------------------------------------------
+// acceleration structure (ESC_STAGE_BVH; the reference's --bvh intent, main.cpp:98-171,
+// aabb.cpp:67-110).  Binary BVH whose node holds the boxes of BOTH children, 64 B = one
+// s_load_dwordx16: a whole wavefront walks the tree together (wave-uniform node index, node in
+// SGPRs, every lane tests its own ray against the two boxes), so the walk needs no per-lane
+// gathers and no per-lane stack.  Leaves are fixed-size blocks of primitives in tree order
+// (2 triangles = 96 B, 4 spheres = 64 B, padded with primitives that can never be hit); `order`
+// maps block slot -> original primitive index (-1 = pad).  Boxes are padded on the host
+// (accel_build.cpp) so that culling can never drop a primitive the exact test would accept.
+// ---------------------------------------------------------------------------------------
+struct alignas(64) BvhNode {
+  float lo0[3], hi0[3]; // child 0
+  float lo1[3], hi1[3]; // child 1
+  int32_t child[2];     // >= 0 node index; < 0 leaf: ~block
+  uint32_t minkey[2];   // smallest primitive key below each child (key = index in triangles-then-
+                        // spheres order, the order occlusion() meets primitives, main.cpp:314-329)
+};
+constexpr int kTriBlock = 2; // triangles per leaf block
+constexpr int kSphBlock = 4; // spheres per leaf block
+constexpr int kBvhMaxDepth = 60; // nodes on a root-to-leaf path; the walk's stack is one VGPR (64 lanes)
+struct alignas(16) TriBlock {
+  DevTri t[kTriBlock];
+};
+struct alignas(64) SphBlock {
+  DevSph s[kSphBlock];
+};
+struct BvhRef {
+  const BvhNode *nodes;
+  const void *blocks;   // TriBlock[] or SphBlock[]
+  const int32_t *order; // block * block_size + slot -> original index, -1 for pads
+  int32_t root;         // as BvhNode::child; meaningless when the primitive count is 0
+  int32_t pad;
+};
+
 struct RenderParams {
   // camera.h:36-39
   float origin[3];
@@ -115,6 +149,7 @@ struct RenderParams {
   // kCounterSets replicas of {primary, hit, shadow rays, any-hit tests, 4 spare}, 64 B each
   unsigned long long *counters;
   HitRec *hits;                 // band-local, n_local_rows * W records (scratch owned by the context)
+  BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only
 };
 
 // pixel tile of one 256-thread workgroup: 2 x 2 waves, each wave (16*PX) x 4 pixels, so the

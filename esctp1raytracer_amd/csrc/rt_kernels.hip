@@ -36,6 +36,7 @@ namespace esc {
 
 constexpr int STAGE_SMEM = 1;
 constexpr int STAGE_LDS = 2;
+constexpr int STAGE_BVH = 3;
 
 struct f3 {
   float x, y, z;
@@ -108,9 +109,8 @@ DEVINL void pack3(const f3 *src, V3<V> (&dst)[NV]) {
 // exact tails (rare paths)
 // ---------------------------------------------------------------------------------------
 
-// ray_triangle.h:21-54 given the fp32 numerators.  Returns true on accept.
-DEVINL bool tri_exact(float detf, float unum, float vnum, float tnum, float tbound, float &t2o,
-                      float &v2o) {
+// ray_triangle.h:21-46 given the fp32 numerators: every reject except the `t2 >= *t` bound.
+DEVINL bool tri_exact_nb(float detf, float unum, float vnum, float tnum, float &t2o, float &v2o) {
   const double eps = (double)FLT_EPSILON;
   double det = (double)detf;                    // :21
   if (det > -eps && det < eps) return false;    // :23-25
@@ -121,6 +121,15 @@ DEVINL bool tri_exact(float detf, float unum, float vnum, float tnum, float tbou
   if (v2 < FLT_EPSILON || u2 + v2 > 1.0f) return false; // :41
   float t2 = (float)((double)tnum * inv_det);   // :45
   if (t2 < FLT_EPSILON) return false;           // :46
+  t2o = t2;
+  v2o = v2;
+  return true;
+}
+// ray_triangle.h:21-54.  Returns true on accept.
+DEVINL bool tri_exact(float detf, float unum, float vnum, float tnum, float tbound, float &t2o,
+                      float &v2o) {
+  float t2, v2;
+  if (!tri_exact_nb(detf, unum, vnum, tnum, t2, v2)) return false;
   if (t2 >= tbound) return false;               // :49
   t2o = t2;
   v2o = v2;
@@ -140,12 +149,18 @@ DEVINL bool tri_candidate(float detf, float unum, float vnum) {
 }
 
 // sphere extension from b and disc; accept iff all three rejects fail.
-DEVINL bool sph_exact(float b, float disc, float tbound, float &t2o) {
+DEVINL bool sph_exact_nb(float b, float disc, float &t2o) { // without the `t2 >= *t` bound
   if (disc < 0.f) return false;
   float sq = sqrtf(disc);
   float t2 = -b - sq;
   if (t2 < FLT_EPSILON) t2 = -b + sq;
   if (t2 < FLT_EPSILON) return false;
+  t2o = t2;
+  return true;
+}
+DEVINL bool sph_exact(float b, float disc, float tbound, float &t2o) {
+  float t2;
+  if (!sph_exact_nb(b, disc, t2)) return false;
   if (t2 >= tbound) return false;
   t2o = t2;
   return true;
@@ -977,6 +992,230 @@ DEVINL int repack_rays(RepackLds &R, int tid) {
 }
 
 // ---------------------------------------------------------------------------------------
+// ESC_STAGE_BVH: wave-synchronous walk of the bounding-volume tree (rt_device.h BvhNode).
+//
+// The 64 rays of a wave (a 16 x 4 pixel block, or the shadow rays leaving it towards one light)
+// travel together: the node index is wave-uniform, the node comes through the scalar cache into
+// SGPRs as one s_load_dwordx16, each lane tests its own ray against the two child boxes, and a
+// child is entered when ANY lane needs it.  The stack is wave-uniform too and lives in the 64
+// lanes of one VGPR (a select to push, v_readlane to pop), so there are no per-lane gathers, no LDS and no
+// divergence inside the walk; the price -- a lane rides along through subtrees only its
+// neighbours need -- is small for rays this coherent.  Leaves are blocks of primitives tested by
+// all lanes with the SAME exact tests as the brute-force loops, so a ray can only ever see a
+// subset of the primitives brute force shows it; the box pads (accel_build.cpp) make sure the
+// primitives it would accept are never culled.
+//
+// The box test is NOT part of the reference arithmetic (it only decides what gets tested), so it
+// may use fused multiply-adds: t = plane * (1/d) - o * (1/d).
+//
+// Three walks share the code:
+//   MODE 0  closest hit (main.cpp:176-192): bound shrinks, near child first, ties go to the
+//           smaller key (= the primitive brute force meets first, ray_triangle.h:49 is strict)
+//   MODE 1  any hit (main.cpp:314-329) when the occluder's t2 is not needed afterwards
+//   MODE 2  first hit in primitive order: occlusion() returns its FIRST occluder's t2 through the
+//           caller's t (quirk S3), and the next light's shadow ray starts from it; subtrees whose
+//           smallest key cannot beat the current one are skipped (BvhNode::minkey)
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
+struct RaySt {
+  float tmax;   // MODE 0: closest t so far (FLT_MAX none); MODE 1/2: the ray's fixed bound
+  float thit;   // MODE 1/2: t2 of the accepted occluder
+  float v;      // MODE 0: barycentric v of the closest triangle (quirk S1)
+  uint32_t key; // accepted primitive, kNoKey = none
+};
+
+template <int MODE> DEVINL void offer(RaySt &s, float t2, float v2, uint32_t key) {
+  if (MODE == 0) {
+    if (t2 < s.tmax || (t2 == s.tmax && s.key != kNoKey && key < s.key)) {
+      s.tmax = t2;
+      s.v = v2;
+      s.key = key;
+    }
+  } else if (MODE == 1) {
+    if (s.key == kNoKey && t2 < s.tmax) {
+      s.key = key;
+      s.thit = t2;
+    }
+  } else {
+    if (t2 < s.tmax && key < s.key) {
+      s.key = key;
+      s.thit = t2;
+    }
+  }
+}
+
+struct RayBox {
+  f3 inv, noinv; // 1/d and -(o/d), d nudged off zero so both stay finite
+};
+DEVINL float safe_rcp(float d) {
+  const float a = (fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d;
+  return 1.0f / a;
+}
+DEVINL RayBox ray_box(f3 o, f3 d) {
+  RayBox r;
+  r.inv = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+  r.noinv = mk(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+  return r;
+}
+// ray segment [0, tmax] against a wave-uniform box; tn = entry distance
+DEVINL bool slab(const float (&lo)[3], const float (&hi)[3], const RayBox &rb, float tmax,
+                 float &tn) {
+  const float x0 = __builtin_fmaf(lo[0], rb.inv.x, rb.noinv.x);
+  const float x1 = __builtin_fmaf(hi[0], rb.inv.x, rb.noinv.x);
+  const float y0 = __builtin_fmaf(lo[1], rb.inv.y, rb.noinv.y);
+  const float y1 = __builtin_fmaf(hi[1], rb.inv.y, rb.noinv.y);
+  const float z0 = __builtin_fmaf(lo[2], rb.inv.z, rb.noinv.z);
+  const float z1 = __builtin_fmaf(hi[2], rb.inv.z, rb.noinv.z);
+  tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.f));
+  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+  return tn <= tf;
+}
+
+// one leaf block of triangles: ray_triangle.h:14-46 per lane, primitives wave-uniform
+template <int MODE>
+DEVINL void leaf_tris(const TriBlock &B, const int32_t *__restrict__ order, int blk, f3 o, f3 d,
+                      RaySt &s, bool act) {
+  float det[kTriBlock], un[kTriBlock], vn[kTriBlock];
+  f3 qv[kTriBlock];
+  bool cand = false;
+#pragma unroll
+  for (int i = 0; i < kTriBlock; ++i) {
+    const f3 e1 = ld3(B.t[i].e1), e2 = ld3(B.t[i].e2), v0 = ld3(B.t[i].v0);
+    const f3 pv = cross(d, e2); // :18
+    det[i] = dot(e1, pv);       // :21
+    const f3 tv = o - v0;       // :29
+    un[i] = dot(tv, pv);        // :32
+    qv[i] = cross(tv, e1);      // :37
+    vn[i] = dot(d, qv[i]);      // :40
+    cand |= act && tri_candidate(det[i], un[i], vn[i]);
+  }
+  if (ANY_LANE_RARE(cand)) {
+#pragma unroll
+    for (int i = 0; i < kTriBlock; ++i) {
+      float t2, v2;
+      if (act && tri_candidate(det[i], un[i], vn[i]) &&
+          tri_exact_nb(det[i], un[i], vn[i], dot(ld3(B.t[i].e2), qv[i]), t2, v2))
+        offer<MODE>(s, t2, v2, (uint32_t)order[blk * kTriBlock + i]);
+    }
+  }
+}
+
+// one leaf block of spheres (SURVEY.md 8(d) test, general form)
+template <int MODE>
+DEVINL void leaf_sphs(const SphBlock &B, const int32_t *__restrict__ order, int blk,
+                      uint32_t key_base, f3 o, f3 d, RaySt &s, bool act) {
+  float b[kSphBlock], q[kSphBlock];
+  float m = -1.f;
+#pragma unroll
+  for (int i = 0; i < kSphBlock; ++i) {
+    const f3 oc = o - mk(B.s[i].cx, B.s[i].cy, B.s[i].cz);
+    b[i] = dot(oc, d);
+    q[i] = b[i] * b[i] - (dot(oc, oc) - B.s[i].r2);
+    m = fmaxf(m, q[i]);
+  }
+  if (ANY_LANE_RARE(act && !(m < 0.f))) {
+#pragma unroll
+    for (int i = 0; i < kSphBlock; ++i) {
+      float t2;
+      if (act && sph_exact_nb(b[i], q[i], t2))
+        offer<MODE>(s, t2, 0.f, key_base + (uint32_t)order[blk * kSphBlock + i]);
+    }
+  }
+}
+
+// Walks one tree.  `alive`: this lane carries a ray.  Leaf(blk, act) tests a leaf block.
+// n_visits counts the nodes + leaves the WAVE went through (wave-uniform).
+template <int MODE, typename Leaf>
+DEVINL void bvh_walk(const BvhRef &R, f3 o, f3 d, RaySt &s, bool alive, Leaf leaf, int &n_visits) {
+  const RayBox rb = ray_box(o, d);
+  const SmemFetch<BvhNode> nodes{R.nodes};
+  int stack = 0; // lane i holds stack entry i
+  const int lane_id = (int)(threadIdx.x & 63u);
+  int sp = 0;
+  int cur = R.root;
+  for (;;) {
+    const bool act = (MODE == 1) ? (alive && s.key == kNoKey) : alive;
+    ++n_visits;
+    if (cur >= 0) {
+      const BvhNode N = nodes(cur);
+      float tn0, tn1;
+      bool h0 = act && slab(N.lo0, N.hi0, rb, s.tmax, tn0);
+      bool h1 = act && slab(N.lo1, N.hi1, rb, s.tmax, tn1);
+      if (MODE == 2) {
+        h0 = h0 && N.minkey[0] < s.key;
+        h1 = h1 && N.minkey[1] < s.key;
+      }
+      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0);
+      const unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1);
+      if (m0 != 0 && m1 != 0) {
+        bool one_first = false;
+        if (MODE == 0) { // near child first: majority vote of the lanes that care
+          const unsigned long long p1 = __builtin_amdgcn_ballot_w64(h1 && (!h0 || tn1 < tn0));
+          const unsigned long long p0 = __builtin_amdgcn_ballot_w64(h0 && (!h1 || tn0 <= tn1));
+          one_first = __popcll(p1) > __popcll(p0);
+        }
+        const int c_near = one_first ? N.child[1] : N.child[0];
+        const int c_far = one_first ? N.child[0] : N.child[1];
+        stack = (lane_id == sp) ? c_far : stack; // "v_writelane": one compare + select
+        ++sp;
+        cur = c_near;
+        continue;
+      }
+      if (m0 != 0) {
+        cur = N.child[0];
+        continue;
+      }
+      if (m1 != 0) {
+        cur = N.child[1];
+        continue;
+      }
+    } else {
+      leaf(~cur, act);
+      if (MODE == 1 && __builtin_amdgcn_ballot_w64(alive && s.key == kNoKey) == 0) return;
+    }
+    if (sp == 0) return;
+    --sp;
+    cur = __builtin_amdgcn_readlane(stack, sp);
+  }
+}
+
+// both trees, triangles first (their keys are smaller: main.cpp:179-186 meets them first)
+// n_tests: leaf primitives tested while this LANE was still undecided; n_swept: leaf primitives
+// the WAVE tested (wave-uniform)
+template <int MODE>
+DEVINL void bvh_trace(const RenderParams &p, f3 o, f3 d, RaySt &s, bool alive, int &n_visits,
+                      int &n_tests, int &n_swept) {
+  if (__builtin_amdgcn_ballot_w64(alive) == 0) return;
+  if (p.n_tri > 0) {
+    const SmemFetch<TriBlock> blocks{reinterpret_cast<const TriBlock *>(p.bvh_tri.blocks)};
+    const int32_t *order = p.bvh_tri.order;
+    bvh_walk<MODE>(p.bvh_tri, o, d, s, alive,
+                   [&](int blk, bool act) {
+                     const TriBlock B = blocks(blk);
+                     leaf_tris<MODE>(B, order, blk, o, d, s, act);
+                     n_tests += act ? kTriBlock : 0;
+                     n_swept += kTriBlock;
+                   },
+                   n_visits);
+  }
+  if (p.n_sph > 0) {
+    if (MODE == 1 && __builtin_amdgcn_ballot_w64(alive && s.key == kNoKey) == 0) return;
+    const SmemFetch<SphBlock> blocks{reinterpret_cast<const SphBlock *>(p.bvh_sph.blocks)};
+    const int32_t *order = p.bvh_sph.order;
+    const uint32_t key_base = (uint32_t)p.n_tri;
+    bvh_walk<MODE>(p.bvh_sph, o, d, s, alive,
+                   [&](int blk, bool act) {
+                     const SphBlock B = blocks(blk);
+                     leaf_sphs<MODE>(B, order, blk, key_base, o, d, s, act);
+                     n_tests += act ? kSphBlock : 0;
+                     n_swept += kSphBlock;
+                   },
+                   n_visits);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // The frame = two kernels on the same stream.
 //
 //   k_primary<STAGE, V, NV>  camera.h:31-34 get_ray + main.cpp:722 closest hit over every
@@ -1054,7 +1293,20 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   // ---- main.cpp:722 closest hit over every primitive
   V3<V> dv[NV];
   pack3<V, NV>(dir, dv);
-  if (STAGE == STAGE_SMEM) {
+  if constexpr (STAGE == STAGE_BVH) {
+    static_assert(PX == 1, "the tree walk carries one ray per lane");
+    RaySt s;
+    s.tmax = (row_ok && w[0] < p.W) ? FLT_MAX : 0.f; // main.cpp:715
+    s.thit = 0.f;
+    s.v = 0.f;
+    s.key = kNoKey;
+    int n_visits = 0, n_tests = 0, n_swept = 0;
+    bvh_trace<0>(p, mk(p.origin[0], p.origin[1], p.origin[2]), dir[0], s, row_ok && w[0] < p.W,
+                 n_visits, n_tests, n_swept);
+    hit[0].t = s.tmax;
+    hit[0].v = s.v;
+    hit[0].idx = (int32_t)s.key; // kNoKey -> -1
+  } else if (STAGE == STAGE_SMEM) {
     closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dv, hit);
     if constexpr (PX == 2) {
       // multiples of 8 through the hand-scheduled packed body, the tail through the generic one
@@ -1183,7 +1435,23 @@ __global__ void __launch_bounds__(256, 6) k_shade(const RenderParams p) {
     }
     if (!(a[0].tb > 0.f)) a[0].tb = 0.f; // dead rays carry tb = 0
     if (p.shadows) { // :772 occlusion(): wave-uniform loops
-      if constexpr (STAGE == STAGE_SMEM) {
+      if constexpr (STAGE == STAGE_BVH) {
+        RaySt s;
+        s.tmax = a[0].tb;
+        s.thit = 0.f;
+        s.v = 0.f;
+        s.key = kNoKey;
+        int n_visits = 0, n_tests = 0;
+        // the occluder's t2 is only ever read by the NEXT light (quirk S3): the last light may
+        // stop at any occluder, the others need the first one in primitive order
+        if (li + 1 < p.n_lights)
+          bvh_trace<2>(p, ro, rL, s, a[0].tb > 0.f, n_visits, n_tests, n_swept);
+        else
+          bvh_trace<1>(p, ro, rL, s, a[0].tb > 0.f, n_visits, n_tests, n_swept);
+        a[0].kocc = (int32_t)s.key; // kNoKey -> -1
+        a[0].tocc = s.thit;
+        n_any += (unsigned)n_tests;
+      } else if constexpr (STAGE == STAGE_SMEM) {
         // ---- segments of the primitive list, undecided rays re-packed in between
         RepackLds &R = lds_rays;
         R.ox[tid] = ro.x; R.oy[tid] = ro.y; R.oz[tid] = ro.z;
@@ -1267,7 +1535,8 @@ __global__ void __launch_bounds__(256, 6) k_shade(const RenderParams p) {
       if (p.shadows) {
         n_shadow += 1u;
         // tests occlusion() runs for this ray: up to and including its first occluder
-        n_any += (a[0].kocc >= 0) ? (unsigned)(a[0].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
+        if (STAGE != STAGE_BVH)
+          n_any += (a[0].kocc >= 0) ? (unsigned)(a[0].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
       }
       if (p.shadows && a[0].kocc >= 0) {
         t = a[0].tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
@@ -1431,14 +1700,17 @@ static void launch_primary(const esc::RenderParams *p, hipStream_t stream) {
   hipLaunchKernelGGL((esc::k_primary<STAGE, V, NV>), dim3(tiles_x * tiles_y), dim3(256), 0, stream, *p);
 }
 
-// stage: 1 SMEM, 2 LDS.  px: pixels per work-item of the primary pass (1, 2 or 4); the shade
+// stage: 1 SMEM, 2 LDS, 3 BVH (px ignored).  px: pixels per work-item of the primary pass (1, 2 or 4); the shade
 // pass always carries one pixel per work-item.
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, hipStream_t stream) {
   if (p->n_local_rows <= 0 || p->W <= 0) return 0;
   using esc::v2f;
   const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
   const int shade_grid = ((p->W + 31) / 32) * tiles_y;
-  if (stage == esc::STAGE_LDS) {
+  if (stage == esc::STAGE_BVH) {
+    launch_primary<esc::STAGE_BVH, float, 1>(p, stream);
+    hipLaunchKernelGGL((esc::k_shade<esc::STAGE_BVH>), dim3(shade_grid), dim3(256), 0, stream, *p);
+  } else if (stage == esc::STAGE_LDS) {
     if (px == 1) launch_primary<esc::STAGE_LDS, float, 1>(p, stream);
     else if (px == 2) launch_primary<esc::STAGE_LDS, v2f, 1>(p, stream);
     else launch_primary<esc::STAGE_LDS, v2f, 2>(p, stream);

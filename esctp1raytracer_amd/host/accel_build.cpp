@@ -1,0 +1,344 @@
+// accel_build.cpp -- binned-SAH BVH over padded primitive boxes (see accel_build.h).
+//
+// Why the boxes are padded.  The kernels must return exactly what the brute-force loops return,
+// and those accept a primitive on the strength of ROUNDED fp32 arithmetic: a ray that misses the
+// geometric primitive by a hair can still be a hit.  A box test may therefore only cull a
+// primitive when the ray stays further away from it than that arithmetic can be wrong.
+// With u = 2^-24 (fp32 unit roundoff) and M = the largest distance between the primitive and any
+// point a ray can start from (OriginBounds):
+//
+//  * sphere (oc = o - c, b = dot(oc,d), disc = b*b - (dot(oc,oc) - r*r)):
+//    three roundings per dot product, one per subtraction and product, |d|^2 within 6u of 1:
+//        |disc - (r^2 - dist^2)| <= 18 u |oc|^2 + 2 u r^2,     dist = distance centre <-> ray line
+//    so disc >= 0 implies dist^2 <= r^2 + 18 u M^2 + ..., and the accepted t2 = -b -+ sqrt(disc)
+//    puts o + t2 d within sqrt(r^2 + 28 u M^2) of the centre.  The box is the cube around the
+//    centre with half-width  R = sqrt(r^2 + 32 u M^2) + 8 u M.
+//
+//  * triangle (ray_triangle.h:7-57, Cramer's rule, numerators in fp32): the numerators
+//    dot(tvec,pvec), dot(dir,qvec) carry an absolute error of ~3 u |tvec| |edge| that does not
+//    shrink with det, so the accepted (u,v) can sit  ~6 u M / sin(theta)  outside the triangle,
+//    theta = angle between ray and triangle plane.  No finite pad covers theta -> 0; the pad used,
+//    2^-12 M, covers every ray steeper than ~1.5e-3 rad by the worst-case bound (about ten times
+//    shallower with typical rounding).  Rays that graze a triangle's plane more closely than that
+//    get rounding noise for (u,v,t) from the reference arithmetic itself; for those -- and only
+//    those -- the BVH mode may in principle cull a hit that brute force reports.  The parity tests
+//    compare whole frames of both modes (tests/test_gpu_parity.py), DESIGN.md states the caveat.
+//
+// The slab test itself (rt_kernels.hip slab()) is off by < 4 u M in position, far inside either
+// pad.  All pads are computed in double and rounded outward.
+#include "accel_build.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace esc {
+
+namespace {
+
+constexpr double kU = 5.9604644775390625e-08; // 2^-24
+
+float down(double x) {
+  float f = (float)x;
+  return ((double)f > x) ? std::nextafterf(f, -FLT_MAX) : f;
+}
+float up(double x) {
+  float f = (float)x;
+  return ((double)f < x) ? std::nextafterf(f, FLT_MAX) : f;
+}
+
+// largest distance from `c` to a corner of the origin bounds
+double far_corner(const OriginBounds &ob, const double c[3]) {
+  double s = 0;
+  for (int a = 0; a < 3; a++) {
+    const double d = std::max(std::fabs(c[a] - ob.lo[a]), std::fabs(c[a] - ob.hi[a]));
+    s += d * d;
+  }
+  return std::sqrt(s);
+}
+
+} // namespace
+
+OriginBounds origin_bounds(const std::vector<DevTri> &tri, const std::vector<DevSph> &sph,
+                           const std::vector<float> &light_points_xyz0, const float origin[3]) {
+  OriginBounds ob;
+  for (int a = 0; a < 3; a++) ob.lo[a] = ob.hi[a] = origin[a];
+  auto grow = [&](double x, double y, double z, double r) {
+    const double p[3] = {x, y, z};
+    for (int a = 0; a < 3; a++) {
+      ob.lo[a] = std::min(ob.lo[a], p[a] - r);
+      ob.hi[a] = std::max(ob.hi[a], p[a] + r);
+    }
+  };
+  for (const DevTri &t : tri) {
+    grow(t.v0[0], t.v0[1], t.v0[2], 0);
+    grow((double)t.v0[0] + t.e1[0], (double)t.v0[1] + t.e1[1], (double)t.v0[2] + t.e1[2], 0);
+    grow((double)t.v0[0] + t.e2[0], (double)t.v0[1] + t.e2[1], (double)t.v0[2] + t.e2[2], 0);
+  }
+  for (const DevSph &s : sph) grow(s.cx, s.cy, s.cz, std::sqrt(std::max(0.0, (double)s.r2)));
+  for (size_t i = 0; i + 4 <= light_points_xyz0.size(); i += 4)
+    grow(light_points_xyz0[i], light_points_xyz0[i + 1], light_points_xyz0[i + 2], 0);
+  double diag = 0;
+  for (int a = 0; a < 3; a++) diag += (ob.hi[a] - ob.lo[a]) * (ob.hi[a] - ob.lo[a]);
+  diag = std::sqrt(diag);
+  const double g = 0.1 * diag + 1e-6;
+  for (int a = 0; a < 3; a++) {
+    ob.lo[a] -= g;
+    ob.hi[a] += g;
+  }
+  return ob;
+}
+
+void triangle_boxes(const std::vector<DevTri> &tri, const OriginBounds &ob,
+                    std::vector<PrimBox> &out) {
+  out.resize(tri.size());
+  for (size_t i = 0; i < tri.size(); i++) {
+    const DevTri &t = tri[i];
+    double lo[3], hi[3], c[3];
+    for (int a = 0; a < 3; a++) {
+      const double p0 = t.v0[a], p1 = (double)t.v0[a] + t.e1[a], p2 = (double)t.v0[a] + t.e2[a];
+      lo[a] = std::min(p0, std::min(p1, p2));
+      hi[a] = std::max(p0, std::max(p1, p2));
+      c[a] = 0.5 * (lo[a] + hi[a]);
+    }
+    double ext = 0;
+    for (int a = 0; a < 3; a++) ext += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+    const double M = far_corner(ob, c) + 0.5 * std::sqrt(ext);
+    const double pad = M * (1.0 / 4096.0);
+    for (int a = 0; a < 3; a++) {
+      out[i].lo[a] = down(lo[a] - pad);
+      out[i].hi[a] = up(hi[a] + pad);
+    }
+  }
+}
+
+void sphere_boxes(const std::vector<DevSph> &sph, const OriginBounds &ob,
+                  std::vector<PrimBox> &out) {
+  out.resize(sph.size());
+  for (size_t i = 0; i < sph.size(); i++) {
+    const DevSph &s = sph[i];
+    const double c[3] = {s.cx, s.cy, s.cz};
+    const double r2 = std::max(0.0, (double)s.r2);
+    const double M = far_corner(ob, c) + std::sqrt(r2);
+    const double R = std::sqrt(r2 * (1.0 + 4 * kU) + 32.0 * kU * M * M) + 8.0 * kU * M;
+    for (int a = 0; a < 3; a++) {
+      out[i].lo[a] = down(c[a] - R);
+      out[i].hi[a] = up(c[a] + R);
+    }
+  }
+}
+
+namespace {
+
+struct Sub { // what a finished subtree reports to its parent
+  int32_t code;
+  float lo[3], hi[3];
+  uint32_t minkey;
+  int depth; // internal nodes on its longest path
+};
+
+struct Builder {
+  const std::vector<PrimBox> &boxes;
+  const int block;
+  const uint32_t key_base;
+  const int max_depth;
+  BuiltBvh &out;
+  std::vector<int32_t> idx;
+  std::vector<float> cen; // 3 per primitive
+
+  // internal levels a count-balanced (median) subtree over n primitives needs
+  int levels_needed(size_t n) const {
+    int l = 0;
+    while (n > (size_t)block) {
+      n = (n + 1) / 2;
+      l++;
+    }
+    return l;
+  }
+
+  static double area(const float lo[3], const float hi[3]) {
+    const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  }
+
+  Sub leaf(size_t b, size_t e) {
+    Sub s;
+    s.code = ~out.n_blocks;
+    s.depth = 0;
+    s.minkey = 0xFFFFFFFFu;
+    for (int a = 0; a < 3; a++) {
+      s.lo[a] = FLT_MAX;
+      s.hi[a] = -FLT_MAX;
+    }
+    for (size_t i = b; i < e; i++) {
+      const int32_t k = idx[i];
+      out.order.push_back(k);
+      s.minkey = std::min(s.minkey, key_base + (uint32_t)k);
+      for (int a = 0; a < 3; a++) {
+        s.lo[a] = std::min(s.lo[a], boxes[k].lo[a]);
+        s.hi[a] = std::max(s.hi[a], boxes[k].hi[a]);
+      }
+    }
+    for (size_t i = e - b; i < (size_t)block; i++) out.order.push_back(-1);
+    out.n_blocks++;
+    return s;
+  }
+
+  // returns the split position m (b < m < e) after partitioning idx[b,e)
+  size_t split(size_t b, size_t e, int depth_used) {
+    const size_t n = e - b;
+    float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = b; i < e; i++)
+      for (int a = 0; a < 3; a++) {
+        const float c = cen[3 * (size_t)idx[i] + a];
+        clo[a] = std::min(clo[a], c);
+        chi[a] = std::max(chi[a], c);
+      }
+    int wide = 0;
+    for (int a = 1; a < 3; a++)
+      if (chi[a] - clo[a] > chi[wide] - clo[wide]) wide = a;
+
+    auto median = [&]() {
+      const size_t m = b + (n + 1) / 2;
+      std::nth_element(idx.begin() + b, idx.begin() + m, idx.begin() + e,
+                       [&](int32_t x, int32_t y) {
+                         const float cx = cen[3 * (size_t)x + wide], cy = cen[3 * (size_t)y + wide];
+                         return cx < cy || (cx == cy && x < y);
+                       });
+      return m;
+    };
+    // depth budget: a median subtree finishes in levels_needed(n) levels; SAH may be lopsided
+    if (depth_used + levels_needed(n) >= max_depth || !(chi[wide] > clo[wide])) return median();
+
+    constexpr int NB = 16;
+    double best = DBL_MAX;
+    int best_axis = -1, best_bin = -1;
+    for (int a = 0; a < 3; a++) {
+      if (!(chi[a] > clo[a])) continue;
+      struct Bin {
+        float lo[3], hi[3];
+        size_t n;
+      } bins[NB];
+      for (auto &bn : bins) {
+        bn.n = 0;
+        for (int k = 0; k < 3; k++) {
+          bn.lo[k] = FLT_MAX;
+          bn.hi[k] = -FLT_MAX;
+        }
+      }
+      const double scale = NB / ((double)chi[a] - clo[a]);
+      for (size_t i = b; i < e; i++) {
+        const int32_t k = idx[i];
+        int bi = (int)(((double)cen[3 * (size_t)k + a] - clo[a]) * scale);
+        bi = std::min(std::max(bi, 0), NB - 1);
+        bins[bi].n++;
+        for (int q = 0; q < 3; q++) {
+          bins[bi].lo[q] = std::min(bins[bi].lo[q], boxes[k].lo[q]);
+          bins[bi].hi[q] = std::max(bins[bi].hi[q], boxes[k].hi[q]);
+        }
+      }
+      double right_area[NB];
+      size_t right_n[NB];
+      {
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        size_t cnt = 0;
+        for (int j = NB - 1; j >= 1; j--) {
+          if (bins[j].n) {
+            for (int q = 0; q < 3; q++) {
+              lo[q] = std::min(lo[q], bins[j].lo[q]);
+              hi[q] = std::max(hi[q], bins[j].hi[q]);
+            }
+            cnt += bins[j].n;
+          }
+          right_area[j] = cnt ? area(lo, hi) : 0.0;
+          right_n[j] = cnt;
+        }
+      }
+      float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+      size_t cnt = 0;
+      for (int j = 0; j + 1 < NB; j++) { // split between bin j and j+1
+        if (bins[j].n) {
+          for (int q = 0; q < 3; q++) {
+            lo[q] = std::min(lo[q], bins[j].lo[q]);
+            hi[q] = std::max(hi[q], bins[j].hi[q]);
+          }
+          cnt += bins[j].n;
+        }
+        const size_t nr = right_n[j + 1];
+        if (cnt == 0 || nr == 0) continue;
+        const double cost = area(lo, hi) * (double)((cnt + block - 1) / block) +
+                            right_area[j + 1] * (double)((nr + block - 1) / block);
+        if (cost < best) {
+          best = cost;
+          best_axis = a;
+          best_bin = j;
+        }
+      }
+    }
+    if (best_axis < 0) return median();
+    const double scale = NB / ((double)chi[best_axis] - clo[best_axis]);
+    auto mid = std::partition(idx.begin() + b, idx.begin() + e, [&](int32_t k) {
+      int bi = (int)(((double)cen[3 * (size_t)k + best_axis] - clo[best_axis]) * scale);
+      bi = std::min(std::max(bi, 0), NB - 1);
+      return bi <= best_bin;
+    });
+    const size_t m = (size_t)(mid - idx.begin());
+    if (m == b || m == e) return median();
+    const size_t big = std::max(m - b, e - m);
+    if (depth_used + 1 + levels_needed(big) > max_depth) return median();
+    return m;
+  }
+
+  Sub build(size_t b, size_t e, int depth_used) {
+    if (e - b <= (size_t)block) return leaf(b, e);
+    const int32_t me = (int32_t)out.nodes.size();
+    out.nodes.emplace_back();
+    const size_t m = split(b, e, depth_used);
+    const Sub L = build(b, m, depth_used + 1);
+    const Sub R = build(m, e, depth_used + 1);
+    BvhNode &N = out.nodes[(size_t)me];
+    std::memcpy(N.lo0, L.lo, 12);
+    std::memcpy(N.hi0, L.hi, 12);
+    std::memcpy(N.lo1, R.lo, 12);
+    std::memcpy(N.hi1, R.hi, 12);
+    N.child[0] = L.code;
+    N.child[1] = R.code;
+    N.minkey[0] = L.minkey;
+    N.minkey[1] = R.minkey;
+    Sub s;
+    s.code = me;
+    s.depth = 1 + std::max(L.depth, R.depth);
+    s.minkey = std::min(L.minkey, R.minkey);
+    for (int a = 0; a < 3; a++) {
+      s.lo[a] = std::min(L.lo[a], R.lo[a]);
+      s.hi[a] = std::max(L.hi[a], R.hi[a]);
+    }
+    return s;
+  }
+};
+
+} // namespace
+
+void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, int max_depth,
+               BuiltBvh &out) {
+  out.nodes.clear();
+  out.order.clear();
+  out.root = 0;
+  out.depth = 0;
+  out.n_blocks = 0;
+  if (boxes.empty()) return;
+  Builder B{boxes, block, key_base, max_depth, out, {}, {}};
+  B.idx.resize(boxes.size());
+  std::iota(B.idx.begin(), B.idx.end(), 0);
+  B.cen.resize(3 * boxes.size());
+  for (size_t i = 0; i < boxes.size(); i++)
+    for (int a = 0; a < 3; a++) B.cen[3 * i + a] = 0.5f * boxes[i].lo[a] + 0.5f * boxes[i].hi[a];
+  out.nodes.reserve(2 * boxes.size() / (size_t)block + 2);
+  const Sub r = B.build(0, boxes.size(), 0);
+  out.root = r.code;
+  out.depth = r.depth;
+}
+
+} // namespace esc

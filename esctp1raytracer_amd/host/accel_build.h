@@ -1,0 +1,52 @@
+// accel_build.h -- host builder of the acceleration structure the ESC_STAGE_BVH kernels walk
+// (rt_device.h BvhNode).  The reference's --bvh path (main.cpp:98-171: median split over
+// triangles sorted by v0.x, aabb.cpp:67-110 slab test) is broken and is not
+// followed; what is kept is its intent -- fewer primitive tests per ray, same image.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../csrc/rt_device.h"
+
+namespace esc {
+
+struct PrimBox {
+  float lo[3], hi[3];
+};
+
+// where ray origins can be: the camera and every surface point of the scene (shadow rays start
+// on the surface that was hit, main.cpp:757-758)
+struct OriginBounds {
+  double lo[3], hi[3];
+  bool contains(const float p[3]) const {
+    for (int a = 0; a < 3; a++)
+      if (!(p[a] >= lo[a] && p[a] <= hi[a])) return false;
+    return true;
+  }
+};
+
+struct BuiltBvh {
+  std::vector<BvhNode> nodes;
+  std::vector<int32_t> order; // n_blocks * block entries: original primitive index, -1 = pad
+  int32_t root = 0;           // >= 0 node index, < 0 ~block (whole set fits one block)
+  int32_t depth = 0;          // most internal nodes on a root-to-leaf path (stack need of the walk)
+  int32_t n_blocks = 0;
+};
+
+// Scene bounds united with `origin`, grown by a tenth of the diagonal.
+OriginBounds origin_bounds(const std::vector<DevTri> &tri, const std::vector<DevSph> &sph,
+                           const std::vector<float> &light_points_xyz0, const float origin[3]);
+
+// Padded primitive bounds (see accel_build.cpp for the error analysis behind the pads).
+void triangle_boxes(const std::vector<DevTri> &tri, const OriginBounds &ob,
+                    std::vector<PrimBox> &out);
+void sphere_boxes(const std::vector<DevSph> &sph, const OriginBounds &ob,
+                  std::vector<PrimBox> &out);
+
+// Binned-SAH build over the boxes; primitive i gets key key_base + i.  Leaves hold up to
+// `block` primitives.  Falls back to median splits wherever SAH would let a path grow past
+// max_depth, so depth <= max_depth always.
+void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, int max_depth,
+               BuiltBvh &out);
+
+} // namespace esc

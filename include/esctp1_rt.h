@@ -183,7 +183,11 @@ enum {
 enum {
   ESC_STAGE_AUTO = 0, /* fastest measured variant per pass */
   ESC_STAGE_SMEM = 1, /* primitives broadcast through the scalar cache into SGPRs */
-  ESC_STAGE_LDS = 2   /* primitives staged in LDS chunks by the workgroup */
+  ESC_STAGE_LDS = 2,  /* primitives staged in LDS chunks by the workgroup */
+  ESC_STAGE_BVH = 3   /* opt-in acceleration structure (what the reference's --bvh flag meant to
+                         be, main.cpp:98-171,331-415): a bounding-volume tree culls primitives
+                         before the same exact tests run, so the image is the brute-force image.
+                         Never chosen by AUTO: BASELINE's configs are brute force. */
 };
 
 typedef struct {
@@ -203,7 +207,8 @@ typedef struct {
   uint64_t hit_pixels;   /* primary rays that hit something */
   uint64_t shadow_rays;  /* occlusion() calls (main.cpp:772): hit pixels x lights */
   uint64_t anyhit_tests; /* primitive tests those calls execute in the reference: up to and
-                            including the first occluder, else every primitive */
+                            including the first occluder, else every primitive.  Under
+                            ESC_STAGE_BVH: the tests the tree walk left for still-undecided rays */
   uint64_t anyhit_lane_tests; /* any-hit tests the GPU actually spent lanes on (64 per wave per
                                  primitive swept, decided or idle lanes included); the ratio
                                  anyhit_tests / anyhit_lane_tests is the lane efficiency of the
@@ -254,6 +259,34 @@ int esc_strip_local_rows(int32_t H, int32_t strip_rows, int32_t first_strip,
 int esc_assemble_strips(esc_context *ctx, const void *d_gathered, int32_t n_ranks,
                         size_t rank_pitch_bytes, int32_t W, int32_t H, int32_t strip_rows,
                         int32_t bytes_per_pixel, void *d_frame);
+/* ---- acceleration structure (ESC_STAGE_BVH) -------------------------------------------
+ * Built on the host from the uploaded scene the first time a frame asks for ESC_STAGE_BVH (or by
+ * esc_build_accel), rebuilt when the camera leaves the region its conservative box pads were
+ * computed for.  The reference times its tree build apart from the render as well
+ * (main.cpp:569-579). */
+typedef struct { /* 64 bytes; boxes of both children live in the parent */
+  float lo0[3], hi0[3];
+  float lo1[3], hi1[3];
+  int32_t child[2];   /* >= 0 node index; < 0 leaf: ~block */
+  uint32_t minkey[2]; /* smallest primitive key (triangles, then spheres) below each child */
+} esc_bvh_node;
+typedef struct {
+  int32_t tri_nodes, tri_blocks, tri_depth, tri_root; /* blocks of 2 triangles */
+  int32_t sph_nodes, sph_blocks, sph_depth, sph_root; /* blocks of 4 spheres */
+  float build_ms; /* host build + upload, last build */
+  int32_t builds; /* how many times this context has built */
+  int32_t reserved[2];
+} esc_accel_info;
+int esc_build_accel(esc_context *ctx, const float origin[3]);
+int esc_get_accel_info(esc_context *ctx, esc_accel_info *out);
+/* Host only (no GPU): the same builder over a scene, for inspection and tests.  which = 0
+ * triangles, 1 spheres.  Any output pointer may be NULL; counts come back in `info`.
+ * prim_boxes receives the padded box of every primitive (lo xyz, hi xyz). */
+int esc_scene_build_accel(const esc_scene *scene, const float origin[3], int32_t which,
+                          esc_accel_info *info, esc_bvh_node *nodes, int64_t nodes_cap,
+                          int32_t *order, int64_t order_cap, float *prim_boxes,
+                          int64_t prim_boxes_cap);
+
 int esc_reset_counters(esc_context *ctx);
 int esc_read_counters(esc_context *ctx, esc_counters *out);
 

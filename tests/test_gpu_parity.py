@@ -365,3 +365,110 @@ def test_c4_full_size_properties(esc, renderer):
         renderer.render_rows(cam, W, H, r0, r0 + H // 2, out_f32=half)
         renderer.synchronize()
         assert_bit_equal(half.cpu().numpy().reshape(H // 2, W, 3), full[r0:r0 + H // 2], "band")
+
+
+# ---------------------------------------------------------------- ESC_STAGE_BVH
+# The tree only decides which primitives get the exact tests; the image must be the brute-force
+# image.  Small scenes are checked against the oracle, full-size frames against the brute-force
+# kernels on the same GPU (every pixel, both the fp32 frame and the quantised bytes).
+@pytest.mark.parametrize("name,eye", [("one", (0, 1, 3)), ("two", (0, 1, 3)),
+                                      ("CornellBox-Original", (0, 1, 2)),
+                                      ("CornellBox-Empty-CO", (0, 1, 3)),
+                                      ("cornell_box", (0, 1, 3))])
+def test_bvh_triangle_scenes_vs_oracle(esc, renderer, name, eye):
+    d = ol.load_dump(name)
+    gpu, u8, ref = render_both(esc, renderer, d, eye, (0, 1, 0), 160, 90,
+                               stage=esc.ESC_STAGE_BVH)
+    assert_bit_equal(gpu, ref, f"bvh/{name}")
+    assert np.array_equal(u8, ol.oracle_quantise(ref))
+    info = renderer.accel_info()
+    assert info["builds"] >= 1 and info["tri_blocks"] > 0
+
+
+@pytest.mark.parametrize("config,n,shadows", [("c2", 100, False), ("c3", 1000, True),
+                                              ("c4", 613, True), ("c4", 10000, True),
+                                              ("c5", 24, True), ("c2", 1, True), ("c2", 5, True)])
+def test_bvh_synthetic_scenes_vs_oracle(esc, renderer, config, n, shadows):
+    sc, d = synthetic_dict(esc, config, n)
+    eye, look = esc.synthetic_view()
+    W, H = (192, 108) if n < 5000 else (96, 54)
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    renderer.reset_counters()
+    gpu, u8 = renderer.render(cam, W, H, want_u8=True, shadows=shadows, stage=esc.ESC_STAGE_BVH)
+    cnt = renderer.counters()
+    ref, rc = ol.oracle_render(d, eye, look, W, H, shadows=shadows, threads=8,
+                               return_counters=True)
+    assert_bit_equal(gpu, ref, f"bvh/{config}/{n}")
+    assert np.array_equal(u8, ol.oracle_quantise(ref))
+    for k in ("primary_rays", "hit_pixels", "shadow_rays"):
+        assert cnt[k] == rc[k]
+    if shadows and n >= 100:  # the tree must leave fewer tests than the reference's linear scan
+        assert cnt["anyhit_tests"] < rc["anyhit_tests"]
+
+
+def test_bvh_two_lights_first_occluder_in_order(esc, renderer):
+    """Quirk S3 carries the FIRST occluder's t2 into the next light's shadow ray: with two
+    lights and many overlapping occluders the walk must report the same one as the linear scan."""
+    d = ol.load_dump("two")
+    rng = np.random.default_rng(11)
+    sph = np.concatenate([rng.uniform(-1.5, 1.5, (120, 1)), rng.uniform(0.1, 1.8, (120, 1)),
+                          rng.uniform(-1.5, 1.0, (120, 1)), rng.uniform(0.05, 0.35, (120, 1))], 1)
+    mats = np.stack([ol.material13(ka=c, kd=c) for c in rng.uniform(0.2, 0.9, (120, 3))])
+    d2 = ol.scene_dict(d["geometry"], sph, mats)
+    assert len(d2["light_sources"]) >= 2
+    for fm, ff in ((esc.ESC_FACE_FIXED, 0), (esc.ESC_FACE_FIXED, 1), (esc.ESC_FACE_HASH, 0)):
+        gpu, u8, ref = render_both(esc, renderer, d2, (0, 1, 3), (0, 1, 0), 200, 120,
+                                   stage=esc.ESC_STAGE_BVH, face_mode=fm, fixed_face=ff, seed=7)
+        assert_bit_equal(gpu, ref, f"bvh/two-lights/{fm}/{ff}")
+
+
+@pytest.mark.parametrize("W,H", [(33, 9), (97, 61), (2, 2), (31, 7)])
+def test_bvh_ragged_sizes(esc, renderer, W, H):
+    d = ol.load_dump("one")
+    gpu, u8, ref = render_both(esc, renderer, d, (0, 1, 3), (0, 1, 0), W, H,
+                               stage=esc.ESC_STAGE_BVH)
+    assert_bit_equal(gpu, ref, f"bvh/{W}x{H}")
+
+
+def test_bvh_camera_move_rebuilds(esc, renderer):
+    """the box pads depend on where rays can start; leaving that region must rebuild"""
+    sc, d = synthetic_dict(esc, "c3", 200)
+    renderer.upload(sc)
+    eye, look = esc.synthetic_view()
+    for e in (eye, (0.5, 3.2, 6.5), (300.0, 40.0, 250.0)):
+        cam = esc.Camera.for_image(e, look, 96, 54)
+        gpu = renderer.render(cam, 96, 54, stage=esc.ESC_STAGE_BVH)
+        ref = ol.oracle_render(d, e, look, 96, 54, threads=8)
+        assert_bit_equal(gpu, ref, f"bvh/eye{e}")
+    assert renderer.accel_info()["builds"] == 2  # the small move stays inside the bounds
+
+
+@pytest.mark.parametrize("config,W,H", [("c2", 1920, 1080), ("c3", 3840, 2160),
+                                        ("c4", 3840, 2160), ("c5", 7680, 4320)])
+def test_bvh_full_size_equals_brute_force(esc, renderer, config, W, H):
+    """BASELINE.json's sizes: every pixel of the BVH frame == the brute-force frame."""
+    import torch
+    sc = esc.Scene.synthetic(config)
+    eye, look = esc.synthetic_view()
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    shadows = config != "c2"
+    a = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda:0")
+    b = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda:0")
+    a8 = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda:0")
+    b8 = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda:0")
+    renderer.reset_counters()
+    renderer.render_rows(cam, W, H, 0, H, out_f32=a, out_u8=a8, shadows=shadows)
+    ca = renderer.counters()
+    renderer.reset_counters()
+    renderer.render_rows(cam, W, H, 0, H, out_f32=b, out_u8=b8, shadows=shadows,
+                         stage=esc.ESC_STAGE_BVH)
+    cb = renderer.counters()
+    renderer.synchronize()
+    nd = int((a.view(torch.int32) != b.view(torch.int32)).sum().item())
+    assert nd == 0, f"{config}: {nd} fp32 values differ between BVH and brute force"
+    assert bool((a8 == b8).all().item())
+    for k in ("primary_rays", "hit_pixels", "shadow_rays"):
+        assert ca[k] == cb[k]
+    assert float(a.sum().item()) > 0
