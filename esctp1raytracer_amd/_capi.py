@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libesctp1rt.so")
+# ESC_LIB_PATH: developer override to time alternative builds of the same library side by side
+LIB_PATH = os.environ.get("ESC_LIB_PATH") or os.path.join(_HERE, "lib", "libesctp1rt.so")
 
 ESC_OK = 0
 ESC_ERR_INVALID = -1

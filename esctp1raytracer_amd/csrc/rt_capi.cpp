@@ -57,6 +57,7 @@ struct esc_context {
   float *d_light_points = nullptr;
   unsigned long long *d_counters = nullptr;
   int n_tri = 0, n_sph = 0, n_lights = 0, n_geom = 0;
+  int min_light_faces = 0; // smallest face count among the lights (bounds ESC_FACE_FIXED)
   bool have_scene = false;
   bool prepared = false;
   float prepared_origin[3] = {0, 0, 0};
@@ -283,6 +284,10 @@ int commit(esc_context *ctx, const Staged &s) {
   ctx->n_sph = (int)s.sph.size();
   ctx->n_lights = (int)s.lights.size();
   ctx->n_geom = s.n_geom;
+  ctx->min_light_faces = 0;
+  for (size_t i = 0; i < s.lights.size(); i++)
+    ctx->min_light_faces = (i == 0) ? s.lights[i].n_faces
+                                    : std::min(ctx->min_light_faces, (int)s.lights[i].n_faces);
   ctx->have_scene = true;
   ctx->prepared = false;
   ctx->h_tri = s.tri;
@@ -549,8 +554,10 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     set_error("render: W*H exceeds the reference's int pixel index (main.cpp:784)");
     return ESC_ERR_INVALID;
   }
-  if (opts->face_mode == ESC_FACE_FIXED && opts->fixed_face < 0) {
-    set_error("render: fixed_face < 0");
+  if (opts->face_mode == ESC_FACE_FIXED &&
+      (opts->fixed_face < 0 || (ctx->n_lights > 0 && opts->fixed_face >= ctx->min_light_faces))) {
+    // main.cpp:743-748 draws faceID in [0, light.face_index.size())
+    set_error("render: fixed_face must be in [0, face count of the smallest light)");
     return ESC_ERR_INVALID;
   }
   if (opts->pixels_per_lane != 0 && opts->pixels_per_lane != 1 && opts->pixels_per_lane != 2 &&

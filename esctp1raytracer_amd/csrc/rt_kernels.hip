@@ -1355,8 +1355,11 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     }
 }
 
+#ifndef ESC_SHADE_WAVES
+#define ESC_SHADE_WAVES 6
+#endif
 template <int STAGE>
-__global__ void __launch_bounds__(256, 6) k_shade(const RenderParams p) {
+__global__ void __launch_bounds__(256, ESC_SHADE_WAVES) k_shade(const RenderParams p) {
   typedef float V;
   constexpr int NV = 1;
   constexpr int TW = 32;
@@ -1381,6 +1384,12 @@ __global__ void __launch_bounds__(256, 6) k_shade(const RenderParams p) {
   if (inside) hr = p.hits[(size_t)lr * p.W + w];
   const bool has_hit = inside && (hr.idx >= 0);
 
+  // the tree walk holds few registers, so its variant keeps the primary direction instead of
+  // recomputing it (two divides, a square root and three more divides each time)
+  f3 dir_kept = mk(0.f, 0.f, 0.f);
+  if constexpr (STAGE == STAGE_BVH)
+    if (has_hit) dir_kept = primary_dir(p, w, h);
+
   // ---- main.cpp:723-738 normal of the hit (per-lane gathers, once per pixel)
   f3 N = mk(0.f, 0.f, 0.f);
   int mi = 0;
@@ -1397,7 +1406,7 @@ __global__ void __launch_bounds__(256, 6) k_shade(const RenderParams p) {
     } else {
       const int k = hr.idx - p.n_tri;
       const DevSph S = p.sph[k];
-      const f3 dir = primary_dir(p, w, h);
+      const f3 dir = (STAGE == STAGE_BVH) ? dir_kept : primary_dir(p, w, h);
       N = normalize((origin + dir * hr.t) - mk(S.cx, S.cy, S.cz)); // extension
       mi = p.sph_mat[k];
     }
@@ -1418,14 +1427,16 @@ __global__ void __launch_bounds__(256, 6) k_shade(const RenderParams p) {
     a[0].tocc = 0.f;
     a[0].kocc = -1;
     if (has_hit) {
+      // x % 1 == 0: a one-face light needs no draw (wave-uniform shortcut)
       const uint32_t face =
           (p.face_mode == 0) ? (uint32_t)p.fixed_face
-                             : face_hash(p.seed, (uint32_t)(h * p.W + w), (uint32_t)li,
-                                         (uint32_t)Lt.n_faces);
+          : (Lt.n_faces == 1) ? 0u
+                              : face_hash(p.seed, (uint32_t)(h * p.W + w), (uint32_t)li,
+                                          (uint32_t)Lt.n_faces);
       const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
       // the primary direction is recomputed here (same ops, same bits) rather than kept in
       // registers across the any-hit loops of the previous light
-      const f3 dir = primary_dir(p, w, h);
+      const f3 dir = (STAGE == STAGE_BVH) ? dir_kept : primary_dir(p, w, h);
       ro = origin + dir * (t - FLT_EPSILON); // :757-758
       rL = P - ro;                           // :759
       const float len = length(rL);          // :761
@@ -1544,10 +1555,14 @@ __global__ void __launch_bounds__(256, 6) k_shade(const RenderParams p) {
         const float d = dot(N, rL); // :775
         if (!(d <= 0.f)) {          // :777
           const DevMat M = p.mat[mi];                  // :768
-          f3 c = (ld3(M.ka) * 0.5f + ld3(M.ke)) / nl; // :769-770
+          // x / 1.0f == x bit for bit, so a single light skips the six correctly rounded divides
+          f3 c = ld3(M.ka) * 0.5f + ld3(M.ke);         // :769-770
+          if (nl != 1.f) c = c / nl;
           const f3 Hh = normalize((N + rL) * 2.f);     // :780
           const float sp = powf(dot(N, Hh), M.Ns);
-          c = c + (ld3(M.kd) * d + ld3(M.ks) * sp) / nl; // :782-783
+          f3 ds = ld3(M.kd) * d + ld3(M.ks) * sp;      // :782-783
+          if (nl != 1.f) ds = ds / nl;
+          c = c + ds;
           r += c.x;                                       // :786-788
           g += c.y;
           b += c.z;

@@ -417,10 +417,17 @@ def test_bvh_two_lights_first_occluder_in_order(esc, renderer):
     mats = np.stack([ol.material13(ka=c, kd=c) for c in rng.uniform(0.2, 0.9, (120, 3))])
     d2 = ol.scene_dict(d["geometry"], sph, mats)
     assert len(d2["light_sources"]) >= 2
-    for fm, ff in ((esc.ESC_FACE_FIXED, 0), (esc.ESC_FACE_FIXED, 1), (esc.ESC_FACE_HASH, 0)):
-        gpu, u8, ref = render_both(esc, renderer, d2, (0, 1, 3), (0, 1, 0), 200, 120,
-                                   stage=esc.ESC_STAGE_BVH, face_mode=fm, fixed_face=ff, seed=7)
-        assert_bit_equal(gpu, ref, f"bvh/two-lights/{fm}/{ff}")
+    for fm, eye in ((esc.ESC_FACE_FIXED, (0, 1, 3)), (esc.ESC_FACE_HASH, (0.3, 1.4, 2.5))):
+        gpu, u8, ref = render_both(esc, renderer, d2, eye, (0, 1, 0), 200, 120,
+                                   stage=esc.ESC_STAGE_BVH, face_mode=fm, fixed_face=0, seed=7)
+        assert_bit_equal(gpu, ref, f"bvh/two-lights/{fm}")
+        brute = renderer.render(esc.Camera.for_image(eye, (0, 1, 0), 200, 120), 200, 120,
+                                face_mode=fm, fixed_face=0, seed=7)
+        assert_bit_equal(gpu, brute, f"bvh vs brute/two-lights/{fm}")
+    # the lights of this scene have one face each: face 1 does not exist (main.cpp:743-748)
+    with pytest.raises(esc.EscError):
+        renderer.render(esc.Camera.for_image((0, 1, 3), (0, 1, 0), 64, 48), 64, 48,
+                        face_mode=esc.ESC_FACE_FIXED, fixed_face=1)
 
 
 @pytest.mark.parametrize("W,H", [(33, 9), (97, 61), (2, 2), (31, 7)])
@@ -436,12 +443,14 @@ def test_bvh_camera_move_rebuilds(esc, renderer):
     sc, d = synthetic_dict(esc, "c3", 200)
     renderer.upload(sc)
     eye, look = esc.synthetic_view()
+    before = renderer.accel_info()["builds"]
     for e in (eye, (0.5, 3.2, 6.5), (300.0, 40.0, 250.0)):
         cam = esc.Camera.for_image(e, look, 96, 54)
         gpu = renderer.render(cam, 96, 54, stage=esc.ESC_STAGE_BVH)
         ref = ol.oracle_render(d, e, look, 96, 54, threads=8)
         assert_bit_equal(gpu, ref, f"bvh/eye{e}")
-    assert renderer.accel_info()["builds"] == 2  # the small move stays inside the bounds
+    # first frame builds, the small move stays inside the bounds, the far one rebuilds
+    assert renderer.accel_info()["builds"] - before == 2
 
 
 @pytest.mark.parametrize("config,W,H", [("c2", 1920, 1080), ("c3", 3840, 2160),

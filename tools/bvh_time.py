@@ -8,6 +8,7 @@ import esctp1raytracer_amd as esc
 cfgs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c2", "c3", "c4", "c5"]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 brute = (len(sys.argv) <= 3) or sys.argv[3] != "nobrute"
+bvh = (len(sys.argv) <= 3) or sys.argv[3] != "nobvh"
 SIZE = {"c2": (1920, 1080), "c3": (3840, 2160), "c4": (3840, 2160), "c5": (7680, 4320)}
 st = torch.cuda.Stream()
 r = esc.Renderer(0, stream=st)
@@ -20,7 +21,7 @@ for cfg in cfgs:
     shadows = cfg != "c2"
     bufs = {}
     for name, stage in (("brute", esc.ESC_STAGE_AUTO), ("bvh", esc.ESC_STAGE_BVH)):
-        if name == "brute" and not brute:
+        if (name == "brute" and not brute) or (name == "bvh" and not bvh):
             continue
         buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
         ts = []
@@ -47,4 +48,5 @@ for cfg in cfgs:
     if len(bufs) == 2:
         nd = int((bufs["brute"].view(torch.int32) != bufs["bvh"].view(torch.int32)).sum().item())
         print(f"{cfg} differing fp32 values: {nd}")
-    print(cfg, "accel", r.accel_info(), flush=True)
+    if bvh:
+        print(cfg, "accel", r.accel_info(), flush=True)
