@@ -22,6 +22,9 @@ static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNod
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevSphP *sph_p, esc::DevSphPairP *sph2_p,
                                   hipStream_t stream);
+extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
+                                      const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
+                                      float ox, float oy, float oz, hipStream_t stream);
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px,
                                  hipStream_t stream);
 extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
@@ -71,6 +74,10 @@ struct esc_context {
   esc::TriBlock *d_bvh_tri_blocks = nullptr;
   esc::SphBlock *d_bvh_sph_blocks = nullptr;
   int32_t *d_bvh_tri_order = nullptr, *d_bvh_sph_order = nullptr;
+  esc::TriBlockP *d_bvh_tri_blocks_p = nullptr; // hoisted for accel_prepared_origin
+  esc::SphBlockP *d_bvh_sph_blocks_p = nullptr;
+  bool accel_prepared = false;
+  float accel_prepared_origin[3] = {0, 0, 0};
   bool accel_valid = false;
   esc::OriginBounds accel_ob{};
   esc_accel_info accel_info{};
@@ -358,6 +365,9 @@ int build_accel_device(esc_context *ctx, const float origin[3]) {
   if ((rc = upload_vec(ctx->d_bvh_sph_nodes, a.sph.nodes, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_bvh_sph_blocks, a.sph_blocks, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_bvh_sph_order, a.sph.order, ctx->stream))) return rc;
+  if ((rc = alloc_dev(ctx->d_bvh_tri_blocks_p, a.tri_blocks.size()))) return rc;
+  if ((rc = alloc_dev(ctx->d_bvh_sph_blocks_p, a.sph_blocks.size()))) return rc;
+  ctx->accel_prepared = false;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const int builds = ctx->accel_info.builds;
   std::memset(&ctx->accel_info, 0, sizeof(ctx->accel_info));
@@ -422,7 +432,8 @@ void esc_context_destroy(esc_context *ctx) {
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
-                  ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_order};
+                  ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_order,
+                  ctx->d_bvh_tri_blocks_p, ctx->d_bvh_sph_blocks_p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -633,10 +644,26 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       int rc = build_accel_device(ctx, cam->origin);
       if (rc) return rc;
     }
-    p.bvh_tri = esc::BvhRef{ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
-                            ctx->accel_info.tri_root, 0};
-    p.bvh_sph = esc::BvhRef{ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_order,
-                            ctx->accel_info.sph_root, 0};
+    if (!ctx->accel_prepared || std::memcmp(ctx->accel_prepared_origin, cam->origin, 12) != 0) {
+      int e = esc_launch_prepare_bvh(
+          reinterpret_cast<const esc::DevTri *>(ctx->d_bvh_tri_blocks),
+          reinterpret_cast<esc::DevTriP *>(ctx->d_bvh_tri_blocks_p),
+          ctx->accel_info.tri_blocks * esc::kTriBlock,
+          reinterpret_cast<const esc::DevSph *>(ctx->d_bvh_sph_blocks),
+          reinterpret_cast<esc::DevSphP *>(ctx->d_bvh_sph_blocks_p),
+          ctx->accel_info.sph_blocks * esc::kSphBlock, cam->origin[0], cam->origin[1],
+          cam->origin[2], ctx->stream);
+      if (e) {
+        set_error(std::string("k_prepare_bvh launch: ") + hipGetErrorString((hipError_t)e));
+        return ESC_ERR_HIP;
+      }
+      std::memcpy(ctx->accel_prepared_origin, cam->origin, 12);
+      ctx->accel_prepared = true;
+    }
+    p.bvh_tri = esc::BvhRef{ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_blocks_p,
+                            ctx->d_bvh_tri_order, ctx->accel_info.tri_root, 0};
+    p.bvh_sph = esc::BvhRef{ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_blocks_p,
+                            ctx->d_bvh_sph_order, ctx->accel_info.sph_root, 0};
     stage = 3;
     px = 1; // a wave walks the tree with its 64 rays
   }

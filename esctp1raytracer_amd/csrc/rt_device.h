@@ -113,9 +113,16 @@ struct alignas(16) TriBlock {
 struct alignas(64) SphBlock {
   DevSph s[kSphBlock];
 };
+struct alignas(64) TriBlockP { // per-frame primary form of a TriBlock
+  DevTriP t[kTriBlock];
+};
+struct alignas(64) SphBlockP {
+  DevSphP s[kSphBlock];
+};
 struct BvhRef {
   const BvhNode *nodes;
   const void *blocks;   // TriBlock[] or SphBlock[]
+  const void *blocks_p; // TriBlockP[] or SphBlockP[]: the same slots, hoisted for the camera origin
   const int32_t *order; // block * block_size + slot -> original index, -1 for pads
   int32_t root;         // as BvhNode::child; meaningless when the primitive count is 0
   int32_t pad;

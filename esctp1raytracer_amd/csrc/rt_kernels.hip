@@ -210,6 +210,39 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, i
   }
 }
 
+// same hoisting for the leaf blocks of the acceleration structure (one thread per block slot)
+__global__ void __launch_bounds__(256)
+k_prepare_bvh(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, int n_tri,
+              const DevSph *__restrict__ sph, DevSphP *__restrict__ sph_p, int n_sph, float ox,
+              float oy, float oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const f3 o = mk(ox, oy, oz);
+  if (i < n_tri) { // a pad slot is all zeros: e1 = 0 keeps det = 0 in this form too
+    const DevTri T = tri[i];
+    const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+    const f3 tv = o - ld3(T.v0);
+    const f3 qv = cross(tv, e1);
+    DevTriP P;
+    P.e2[0] = e2.x; P.e2[1] = e2.y; P.e2[2] = e2.z;
+    P.e1[0] = e1.x; P.e1[1] = e1.y; P.e1[2] = e1.z;
+    P.tv[0] = tv.x; P.tv[1] = tv.y; P.tv[2] = tv.z;
+    P.qv[0] = qv.x; P.qv[1] = qv.y; P.qv[2] = qv.z;
+    P.tnum = dot(e2, qv);
+    P.pad[0] = P.pad[1] = P.pad[2] = 0.f;
+    tri_p[i] = P;
+  }
+  if (i < n_sph) { // a pad slot has r2 = -inf: cc = +inf, disc = -inf
+    const DevSph S = sph[i];
+    const f3 oc = o - mk(S.cx, S.cy, S.cz);
+    DevSphP P;
+    P.ocx = oc.x;
+    P.ocy = oc.y;
+    P.ocz = oc.z;
+    P.cc = dot(oc, oc) - S.r2;
+    sph_p[i] = P;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // primitive loops.  `rec(k)` yields record k wave-uniformly (SGPRs or LDS broadcast).
 //
@@ -1072,16 +1105,16 @@ DEVINL bool slab(const float (&lo)[3], const float (&hi)[3], const RayBox &rb, f
   return tn <= tf;
 }
 
-// one leaf block of triangles: ray_triangle.h:14-46 per lane, primitives wave-uniform
-template <int MODE>
-DEVINL void leaf_tris(const TriBlock &B, const int32_t *__restrict__ order, int blk, f3 o, f3 d,
-                      RaySt &s, bool act) {
-  float det[kTriBlock], un[kTriBlock], vn[kTriBlock];
-  f3 qv[kTriBlock];
+// N wave-uniform triangles against one ray per lane: ray_triangle.h:14-46.  key(i) names slot i
+// (only evaluated for an accept).  General form: any origin.
+template <int MODE, int N, typename KeyFn>
+DEVINL void test_tris_general(const DevTri (&T)[N], KeyFn key, f3 o, f3 d, RaySt &s, bool act) {
+  float det[N], un[N], vn[N];
+  f3 qv[N];
   bool cand = false;
 #pragma unroll
-  for (int i = 0; i < kTriBlock; ++i) {
-    const f3 e1 = ld3(B.t[i].e1), e2 = ld3(B.t[i].e2), v0 = ld3(B.t[i].v0);
+  for (int i = 0; i < N; ++i) {
+    const f3 e1 = ld3(T[i].e1), e2 = ld3(T[i].e2), v0 = ld3(T[i].v0);
     const f3 pv = cross(d, e2); // :18
     det[i] = dot(e1, pv);       // :21
     const f3 tv = o - v0;       // :29
@@ -1092,34 +1125,74 @@ DEVINL void leaf_tris(const TriBlock &B, const int32_t *__restrict__ order, int 
   }
   if (ANY_LANE_RARE(cand)) {
 #pragma unroll
-    for (int i = 0; i < kTriBlock; ++i) {
+    for (int i = 0; i < N; ++i) {
       float t2, v2;
       if (act && tri_candidate(det[i], un[i], vn[i]) &&
-          tri_exact_nb(det[i], un[i], vn[i], dot(ld3(B.t[i].e2), qv[i]), t2, v2))
-        offer<MODE>(s, t2, v2, (uint32_t)order[blk * kTriBlock + i]);
+          tri_exact_nb(det[i], un[i], vn[i], dot(ld3(T[i].e2), qv[i]), t2, v2))
+        offer<MODE>(s, t2, v2, key(i));
+    }
+  }
+}
+// Primary form: tvec, qvec and dot(edge2,qvec) hoisted per triangle (k_prepare_*), same bits.
+template <int MODE, int N, typename KeyFn>
+DEVINL void test_tris_primary(const DevTriP (&T)[N], KeyFn key, f3 d, RaySt &s, bool act) {
+  float det[N], un[N], vn[N];
+  bool cand = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const f3 pv = cross(d, ld3(T[i].e2)); // :18
+    det[i] = dot(ld3(T[i].e1), pv);       // :21
+    un[i] = dot(ld3(T[i].tv), pv);        // :32
+    const f3 qv = ld3(T[i].qv);
+    vn[i] = (qv.x * d.x + qv.y * d.y) + qv.z * d.z; // :40 (products commute, sum order kept)
+    cand |= act && tri_candidate(det[i], un[i], vn[i]);
+  }
+  if (ANY_LANE_RARE(cand)) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float t2, v2;
+      if (act && tri_candidate(det[i], un[i], vn[i]) &&
+          tri_exact_nb(det[i], un[i], vn[i], T[i].tnum, t2, v2))
+        offer<MODE>(s, t2, v2, key(i));
     }
   }
 }
 
-// one leaf block of spheres (SURVEY.md 8(d) test, general form)
-template <int MODE>
-DEVINL void leaf_sphs(const SphBlock &B, const int32_t *__restrict__ order, int blk,
-                      uint32_t key_base, f3 o, f3 d, RaySt &s, bool act) {
-  float b[kSphBlock], q[kSphBlock];
+// N wave-uniform spheres (SURVEY.md 8(d) test), general and primary (oc, cc hoisted) forms
+template <int MODE, int N, typename KeyFn>
+DEVINL void test_sphs_general(const DevSph (&S)[N], KeyFn key, f3 o, f3 d, RaySt &s, bool act) {
+  float b[N], q[N];
   float m = -1.f;
 #pragma unroll
-  for (int i = 0; i < kSphBlock; ++i) {
-    const f3 oc = o - mk(B.s[i].cx, B.s[i].cy, B.s[i].cz);
+  for (int i = 0; i < N; ++i) {
+    const f3 oc = o - mk(S[i].cx, S[i].cy, S[i].cz);
     b[i] = dot(oc, d);
-    q[i] = b[i] * b[i] - (dot(oc, oc) - B.s[i].r2);
+    q[i] = b[i] * b[i] - (dot(oc, oc) - S[i].r2);
     m = fmaxf(m, q[i]);
   }
   if (ANY_LANE_RARE(act && !(m < 0.f))) {
 #pragma unroll
-    for (int i = 0; i < kSphBlock; ++i) {
+    for (int i = 0; i < N; ++i) {
       float t2;
-      if (act && sph_exact_nb(b[i], q[i], t2))
-        offer<MODE>(s, t2, 0.f, key_base + (uint32_t)order[blk * kSphBlock + i]);
+      if (act && sph_exact_nb(b[i], q[i], t2)) offer<MODE>(s, t2, 0.f, key(i));
+    }
+  }
+}
+template <int MODE, int N, typename KeyFn>
+DEVINL void test_sphs_primary(const DevSphP (&S)[N], KeyFn key, f3 d, RaySt &s, bool act) {
+  float b[N], q[N];
+  float m = -1.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    b[i] = (S[i].ocx * d.x + S[i].ocy * d.y) + S[i].ocz * d.z;
+    q[i] = b[i] * b[i] - S[i].cc;
+    m = fmaxf(m, q[i]);
+  }
+  if (ANY_LANE_RARE(act && !(m < 0.f))) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float t2;
+      if (act && sph_exact_nb(b[i], q[i], t2)) offer<MODE>(s, t2, 0.f, key(i));
     }
   }
 }
@@ -1182,18 +1255,42 @@ DEVINL void bvh_walk(const BvhRef &R, f3 o, f3 d, RaySt &s, bool alive, Leaf lea
 
 // both trees, triangles first (their keys are smaller: main.cpp:179-186 meets them first)
 // n_tests: leaf primitives tested while this LANE was still undecided; n_swept: leaf primitives
-// the WAVE tested (wave-uniform)
-template <int MODE>
+// the WAVE tested (wave-uniform).  PRIMARY: every ray starts at the camera, so the leaves are read
+// in their hoisted per-frame form (k_prepare_bvh).  A handful of triangles (a floor, a light)
+// is not worth a tree: up to kTinyTris are simply tested in index order from the flat tables.
+constexpr int kTinyTris = 4;
+template <int MODE, bool PRIMARY>
 DEVINL void bvh_trace(const RenderParams &p, f3 o, f3 d, RaySt &s, bool alive, int &n_visits,
                       int &n_tests, int &n_swept) {
   if (__builtin_amdgcn_ballot_w64(alive) == 0) return;
-  if (p.n_tri > 0) {
-    const SmemFetch<TriBlock> blocks{reinterpret_cast<const TriBlock *>(p.bvh_tri.blocks)};
+  if (p.n_tri > 0 && p.n_tri <= kTinyTris) {
+    for (int k = 0; k < p.n_tri; ++k) {
+      const bool act = (MODE == 1) ? (alive && s.key == kNoKey) : alive;
+      auto key = [&](int) { return (uint32_t)k; };
+      if (PRIMARY) {
+        const DevTriP T[1] = {SmemFetch<DevTriP>{p.tri_p}(k)};
+        test_tris_primary<MODE, 1>(T, key, d, s, act);
+      } else {
+        const DevTri T[1] = {SmemFetch<DevTri>{p.tri}(k)};
+        test_tris_general<MODE, 1>(T, key, o, d, s, act);
+      }
+      n_tests += act ? 1 : 0;
+      n_swept += 1;
+    }
+  } else if (p.n_tri > 0) {
     const int32_t *order = p.bvh_tri.order;
     bvh_walk<MODE>(p.bvh_tri, o, d, s, alive,
                    [&](int blk, bool act) {
-                     const TriBlock B = blocks(blk);
-                     leaf_tris<MODE>(B, order, blk, o, d, s, act);
+                     auto key = [&](int i) { return (uint32_t)order[blk * kTriBlock + i]; };
+                     if (PRIMARY) {
+                       const TriBlockP B = SmemFetch<TriBlockP>{
+                           reinterpret_cast<const TriBlockP *>(p.bvh_tri.blocks_p)}(blk);
+                       test_tris_primary<MODE, kTriBlock>(B.t, key, d, s, act);
+                     } else {
+                       const TriBlock B = SmemFetch<TriBlock>{
+                           reinterpret_cast<const TriBlock *>(p.bvh_tri.blocks)}(blk);
+                       test_tris_general<MODE, kTriBlock>(B.t, key, o, d, s, act);
+                     }
                      n_tests += act ? kTriBlock : 0;
                      n_swept += kTriBlock;
                    },
@@ -1201,13 +1298,22 @@ DEVINL void bvh_trace(const RenderParams &p, f3 o, f3 d, RaySt &s, bool alive, i
   }
   if (p.n_sph > 0) {
     if (MODE == 1 && __builtin_amdgcn_ballot_w64(alive && s.key == kNoKey) == 0) return;
-    const SmemFetch<SphBlock> blocks{reinterpret_cast<const SphBlock *>(p.bvh_sph.blocks)};
     const int32_t *order = p.bvh_sph.order;
     const uint32_t key_base = (uint32_t)p.n_tri;
     bvh_walk<MODE>(p.bvh_sph, o, d, s, alive,
                    [&](int blk, bool act) {
-                     const SphBlock B = blocks(blk);
-                     leaf_sphs<MODE>(B, order, blk, key_base, o, d, s, act);
+                     auto key = [&](int i) {
+                       return key_base + (uint32_t)order[blk * kSphBlock + i];
+                     };
+                     if (PRIMARY) {
+                       const SphBlockP B = SmemFetch<SphBlockP>{
+                           reinterpret_cast<const SphBlockP *>(p.bvh_sph.blocks_p)}(blk);
+                       test_sphs_primary<MODE, kSphBlock>(B.s, key, d, s, act);
+                     } else {
+                       const SphBlock B = SmemFetch<SphBlock>{
+                           reinterpret_cast<const SphBlock *>(p.bvh_sph.blocks)}(blk);
+                       test_sphs_general<MODE, kSphBlock>(B.s, key, o, d, s, act);
+                     }
                      n_tests += act ? kSphBlock : 0;
                      n_swept += kSphBlock;
                    },
@@ -1301,7 +1407,7 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     s.v = 0.f;
     s.key = kNoKey;
     int n_visits = 0, n_tests = 0, n_swept = 0;
-    bvh_trace<0>(p, mk(p.origin[0], p.origin[1], p.origin[2]), dir[0], s, row_ok && w[0] < p.W,
+    bvh_trace<0, true>(p, mk(p.origin[0], p.origin[1], p.origin[2]), dir[0], s, row_ok && w[0] < p.W,
                  n_visits, n_tests, n_swept);
     hit[0].t = s.tmax;
     hit[0].v = s.v;
@@ -1456,9 +1562,9 @@ __global__ void __launch_bounds__(256, ESC_SHADE_WAVES) k_shade(const RenderPara
         // the occluder's t2 is only ever read by the NEXT light (quirk S3): the last light may
         // stop at any occluder, the others need the first one in primitive order
         if (li + 1 < p.n_lights)
-          bvh_trace<2>(p, ro, rL, s, a[0].tb > 0.f, n_visits, n_tests, n_swept);
+          bvh_trace<2, false>(p, ro, rL, s, a[0].tb > 0.f, n_visits, n_tests, n_swept);
         else
-          bvh_trace<1>(p, ro, rL, s, a[0].tb > 0.f, n_visits, n_tests, n_swept);
+          bvh_trace<1, false>(p, ro, rL, s, a[0].tb > 0.f, n_visits, n_tests, n_swept);
         a[0].kocc = (int32_t)s.key; // kNoKey -> -1
         a[0].tocc = s.thit;
         n_any += (unsigned)n_tests;
@@ -1704,6 +1810,17 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
                      tri_p, p->n_tri, p->sph, sph_p, sph2_p, p->n_sph, p->origin[0], p->origin[1],
                      p->origin[2]);
+  return (int)hipGetLastError();
+}
+
+// hoisted leaf blocks for rays leaving (ox,oy,oz); n_* count block SLOTS (pads included)
+extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
+                                      const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
+                                      float ox, float oy, float oz, hipStream_t stream) {
+  const int n = std::max(n_tri, n_sph);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(esc::k_prepare_bvh, dim3((n + 255) / 256), dim3(256), 0, stream, tri, tri_p,
+                     n_tri, sph, sph_p, n_sph, ox, oy, oz);
   return (int)hipGetLastError();
 }
 
