@@ -1199,54 +1199,59 @@ DEVINL void test_sphs_primary(const DevSphP (&S)[N], KeyFn key, f3 d, RaySt &s, 
 
 // Walks one tree.  `alive`: this lane carries a ray.  Leaf(blk, act) tests a leaf block.
 // n_visits counts the nodes + leaves the WAVE went through (wave-uniform).
+// Lane predicates are kept as 64-bit wave masks (SGPR pairs) and combined on the scalar unit:
+// the box tests run for every lane unconditionally and their ballots are masked afterwards.
 template <int MODE, typename Leaf>
 DEVINL void bvh_walk(const BvhRef &R, f3 o, f3 d, RaySt &s, bool alive, Leaf leaf, int &n_visits) {
+  typedef unsigned long long mask_t;
   const RayBox rb = ray_box(o, d);
   const SmemFetch<BvhNode> nodes{R.nodes};
+  const mask_t alive_m = __builtin_amdgcn_ballot_w64(alive);
   int stack = 0; // lane i holds stack entry i
   const int lane_id = (int)(threadIdx.x & 63u);
   int sp = 0;
   int cur = R.root;
   for (;;) {
-    const bool act = (MODE == 1) ? (alive && s.key == kNoKey) : alive;
-    ++n_visits;
-    if (cur >= 0) {
+    while (cur >= 0) {
+      ++n_visits;
       const BvhNode N = nodes(cur);
+      mask_t act_m = alive_m;
+      if (MODE == 1) act_m = __builtin_amdgcn_ballot_w64(alive && s.key == kNoKey);
       float tn0, tn1;
-      bool h0 = act && slab(N.lo0, N.hi0, rb, s.tmax, tn0);
-      bool h1 = act && slab(N.lo1, N.hi1, rb, s.tmax, tn1);
+      const bool b0 = slab(N.lo0, N.hi0, rb, s.tmax, tn0);
+      const bool b1 = slab(N.lo1, N.hi1, rb, s.tmax, tn1);
+      mask_t m0 = __builtin_amdgcn_ballot_w64(b0) & act_m;
+      mask_t m1 = __builtin_amdgcn_ballot_w64(b1) & act_m;
       if (MODE == 2) {
-        h0 = h0 && N.minkey[0] < s.key;
-        h1 = h1 && N.minkey[1] < s.key;
+        m0 &= __builtin_amdgcn_ballot_w64(N.minkey[0] < s.key);
+        m1 &= __builtin_amdgcn_ballot_w64(N.minkey[1] < s.key);
       }
-      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0);
-      const unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1);
       if (m0 != 0 && m1 != 0) {
         bool one_first = false;
         if (MODE == 0) { // near child first: majority vote of the lanes that care
-          const unsigned long long p1 = __builtin_amdgcn_ballot_w64(h1 && (!h0 || tn1 < tn0));
-          const unsigned long long p0 = __builtin_amdgcn_ballot_w64(h0 && (!h1 || tn0 <= tn1));
+          const mask_t lt = __builtin_amdgcn_ballot_w64(tn1 < tn0);
+          const mask_t both = m0 & m1;
+          const mask_t p1 = (m1 & ~m0) | (both & lt);
+          const mask_t p0 = (m0 & ~m1) | (both & ~lt);
           one_first = __popcll(p1) > __popcll(p0);
         }
-        const int c_near = one_first ? N.child[1] : N.child[0];
         const int c_far = one_first ? N.child[0] : N.child[1];
         stack = (lane_id == sp) ? c_far : stack; // "v_writelane": one compare + select
         ++sp;
-        cur = c_near;
-        continue;
-      }
-      if (m0 != 0) {
+        cur = one_first ? N.child[1] : N.child[0];
+      } else if (m0 != 0) {
         cur = N.child[0];
-        continue;
-      }
-      if (m1 != 0) {
+      } else if (m1 != 0) {
         cur = N.child[1];
-        continue;
+      } else {
+        if (sp == 0) return;
+        --sp;
+        cur = __builtin_amdgcn_readlane(stack, sp);
       }
-    } else {
-      leaf(~cur, act);
-      if (MODE == 1 && __builtin_amdgcn_ballot_w64(alive && s.key == kNoKey) == 0) return;
     }
+    ++n_visits;
+    leaf(~cur, (MODE == 1) ? (alive && s.key == kNoKey) : alive);
+    if (MODE == 1 && __builtin_amdgcn_ballot_w64(alive && s.key == kNoKey) == 0) return;
     if (sp == 0) return;
     --sp;
     cur = __builtin_amdgcn_readlane(stack, sp);
