@@ -950,6 +950,9 @@ void trace(int32_t image_width, int32_t image_height, ispc_cam *cam, int32_t num
     o.shadows = 1;
     o.face_mode = ESC_FACE_HASH; // == face 0 for single-face lights
     o.seed = 0;
+    // the 12-argument seam has no room for options: $ESC_TRACE_STAGE=bvh opts into the tree
+    const char *st = std::getenv("ESC_TRACE_STAGE");
+    if (st && std::strcmp(st, "bvh") == 0) o.stage = ESC_STAGE_BVH;
     rc = esc_render_frame_host(ctx, &c, image_width, image_height, &o, return_image, nullptr);
   }
   if (rc != ESC_OK) {

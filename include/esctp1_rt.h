@@ -162,7 +162,8 @@ void esc_new_ispc_cam(ispc_cam *cam, const float lookfrom[3], const float lookat
  * reference accumulates into uninitialised memory, defect I3).  Synchronous; renders on
  * device 0 (or $ESC_DEVICE); errors are reported on stderr and leave the image zeroed,
  * because the replaced function returns void.  Multi-face lights use the counter-based
- * face choice below with seed 0.
+ * face choice below with seed 0.  $ESC_TRACE_STAGE=bvh renders through the opt-in
+ * acceleration structure (ESC_STAGE_BVH below) -- same image.
  * ---------------------------------------------------------------------------------- */
 void trace(int32_t image_width, int32_t image_height, ispc_cam *cam, int32_t num_triangles,
            ispc_triangle triangles[], int32_t num_lights, ispc_light lights[],

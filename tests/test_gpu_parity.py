@@ -318,6 +318,13 @@ def test_trace_drop_in(esc, renderer):
     flat_sorted = sc.flatten_ispc(sort_by_centroid_x=True)
     img2 = esc.trace(W, H, (0, 1, 2), (0, 1, 0), (0, 1, 0), 60.0, aspect, flat_sorted)
     assert np.allclose(img2, ref, atol=0, rtol=0) or (bits(img2) != bits(ref)).mean() < 0.01
+    import os
+    os.environ["ESC_TRACE_STAGE"] = "bvh"  # the seam's only way to opt into the tree
+    try:
+        img3 = esc.trace(W, H, (0, 1, 2), (0, 1, 0), (0, 1, 0), 60.0, aspect, flat)
+    finally:
+        del os.environ["ESC_TRACE_STAGE"]
+    assert_bit_equal(img3, ref, "trace() through the BVH")
 
 
 def test_empty_and_missing(esc, renderer):
@@ -436,6 +443,16 @@ def test_bvh_ragged_sizes(esc, renderer, W, H):
     gpu, u8, ref = render_both(esc, renderer, d, (0, 1, 3), (0, 1, 0), W, H,
                                stage=esc.ESC_STAGE_BVH)
     assert_bit_equal(gpu, ref, f"bvh/{W}x{H}")
+
+
+def test_bvh_multi_band_single_process(esc):
+    """esc_render_frame_multi: every band's context builds its own tree"""
+    sc, d = synthetic_dict(esc, "c3", 400)
+    eye, look = esc.synthetic_view()
+    cam = esc.Camera.for_image(eye, look, 200, 120)
+    img, _, _ = esc.render_multi(sc, cam, 200, 120, 3, stage=esc.ESC_STAGE_BVH)
+    ref = ol.oracle_render(d, eye, look, 200, 120, threads=8)
+    assert_bit_equal(img, ref, "bvh/render_multi")
 
 
 def test_bvh_camera_move_rebuilds(esc, renderer):

@@ -239,16 +239,17 @@ def test_viewer_cli_surface():
 
 
 def test_host_code_under_sanitizers(tmp_path, golden_dir):
-    """scene model, loader, synthetic scenes, flatten and PPM writer under ASan + UBSan (CPU
+    """scene model, loader, synthetic scenes, flatten, PPM writer and BVH builder under ASan + UBSan (CPU
     build of the host half only; the GPU pool offers no sanitizer runs)"""
     exe = tmp_path / "host_sanitize"
     src = [os.path.join(ROOT, "tools", "host_sanitize.cpp")] + [
         os.path.join(ROOT, "esctp1raytracer_amd", "host", f)
-        for f in ("host_core.cpp", "obj_loader.cpp", "synth.cpp")]
+        for f in ("host_core.cpp", "obj_loader.cpp", "synth.cpp", "accel_build.cpp")]
     b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
                         "-fno-omit-frame-pointer", "-ffp-contract=off",
                         "-I" + os.path.join(ROOT, "include"),
-                        "-I" + os.path.join(ROOT, "esctp1raytracer_amd", "host")] + src +
+                        "-I" + os.path.join(ROOT, "esctp1raytracer_amd", "host"),
+                        "-I" + os.path.join(ROOT, "esctp1raytracer_amd", "csrc")] + src +
                        ["-o", str(exe)], capture_output=True, text=True)
     if b.returncode != 0 and "sanitize" in b.stderr:
         pytest.skip("sanitizer runtime not available")

@@ -6,7 +6,31 @@
 #include <string>
 #include <vector>
 
+#include "accel_build.h"
 #include "esctp1_rt.h"
+
+// acceleration-structure builder (host/accel_build.cpp) on awkward inputs: every primitive must
+// come out in exactly one leaf slot and the depth must stay inside the walk's stack
+static int check_bvh(const std::vector<esc::PrimBox> &boxes, int block) {
+  esc::BuiltBvh b;
+  esc::build_bvh(boxes, block, 7u, esc::kBvhMaxDepth, b);
+  std::vector<int> seen(boxes.size(), 0);
+  for (int32_t k : b.order)
+    if (k >= 0) {
+      if ((size_t)k >= boxes.size()) return 1;
+      seen[(size_t)k]++;
+    }
+  for (int c : seen)
+    if (c != 1) return 1;
+  if (b.depth > esc::kBvhMaxDepth) return 1;
+  if (b.order.size() != (size_t)b.n_blocks * (size_t)block) return 1;
+  for (const esc::BvhNode &n : b.nodes)
+    for (int c = 0; c < 2; c++) {
+      const int32_t ch = n.child[c];
+      if (ch >= 0 ? (size_t)ch >= b.nodes.size() : (~ch) >= b.n_blocks) return 1;
+    }
+  return 0;
+}
 
 int main(int argc, char **argv) {
   int failures = 0;
@@ -42,6 +66,31 @@ int main(int argc, char **argv) {
     esc_scene *sc = esc_scene_new();
     if (esc_scene_synthetic(sc, cfg, std::strcmp(cfg, "c5") ? 0 : 16) != ESC_OK) failures++;
     esc_scene_free(sc);
+  }
+  {
+    unsigned long long z = 12345;
+    auto rnd = [&]() {
+      z = z * 6364136223846793005ull + 1442695040888963407ull;
+      return (float)((z >> 40) & 0xFFFF) / 65535.0f;
+    };
+    for (int n : {0, 1, 2, 3, 5, 64, 1000}) {
+      std::vector<esc::PrimBox> scattered((size_t)n), same((size_t)n), line((size_t)n);
+      float x = 1e-3f;
+      for (int i = 0; i < n; i++) {
+        for (int a = 0; a < 3; a++) {
+          const float c = rnd() * 100.f - 50.f, h = rnd();
+          scattered[(size_t)i].lo[a] = c - h;
+          scattered[(size_t)i].hi[a] = c + h;
+          same[(size_t)i].lo[a] = -1.f;
+          same[(size_t)i].hi[a] = 1.f;
+          line[(size_t)i].lo[a] = a ? 0.f : x;
+          line[(size_t)i].hi[a] = a ? 0.f : x * 1.0001f;
+        }
+        x *= 1.05f; // geometric spacing: plain SAH would peel one box per level
+      }
+      for (int block : {2, 4})
+        failures += check_bvh(scattered, block) + check_bvh(same, block) + check_bvh(line, block);
+    }
   }
   esc_scene *bad = esc_scene_new();
   if (esc_scene_synthetic(bad, "nope", 0) == ESC_OK) failures++;
