@@ -25,6 +25,8 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
+extern "C" int esc_launch_bin_primary(const esc::RenderParams *p, const esc::PrimBoxDev *tri_boxes,
+                                      const esc::PrimBoxDev *sph_boxes, hipStream_t stream);
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px,
                                  hipStream_t stream);
 extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
@@ -78,6 +80,10 @@ struct esc_context {
   esc::SphBlockP *d_bvh_sph_blocks_p = nullptr;
   bool accel_prepared = false;
   float accel_prepared_origin[3] = {0, 0, 0};
+  // screen-space bins of the primary pass (rt_device.h BinGrid)
+  esc::PrimBoxDev *d_tri_boxes = nullptr, *d_sph_boxes = nullptr;
+  int32_t *d_bin_hdr = nullptr, *d_bin_tri_ids = nullptr, *d_bin_sph_ids = nullptr;
+  int bin_tiles_x = 0, bin_groups_y = 0;
   bool accel_valid = false;
   esc::OriginBounds accel_ob{};
   esc_accel_info accel_info{};
@@ -365,6 +371,16 @@ int build_accel_device(esc_context *ctx, const float origin[3]) {
   if ((rc = upload_vec(ctx->d_bvh_sph_nodes, a.sph.nodes, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_bvh_sph_blocks, a.sph_blocks, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_bvh_sph_order, a.sph.order, ctx->stream))) return rc;
+  static_assert(sizeof(esc::PrimBox) == sizeof(esc::PrimBoxDev), "same six floats");
+  {
+    std::vector<esc::PrimBoxDev> tb(a.tri_boxes.size()), sb(a.sph_boxes.size());
+    if (!tb.empty()) std::memcpy(tb.data(), a.tri_boxes.data(), tb.size() * sizeof(esc::PrimBoxDev));
+    if (!sb.empty()) std::memcpy(sb.data(), a.sph_boxes.data(), sb.size() * sizeof(esc::PrimBoxDev));
+    if ((rc = upload_vec(ctx->d_tri_boxes, tb, ctx->stream))) return rc;
+    if ((rc = upload_vec(ctx->d_sph_boxes, sb, ctx->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // tb / sb die here
+  }
+  ctx->bin_tiles_x = ctx->bin_groups_y = 0; // bins hold ids of the old scene: start over
   if ((rc = alloc_dev(ctx->d_bvh_tri_blocks_p, a.tri_blocks.size()))) return rc;
   if ((rc = alloc_dev(ctx->d_bvh_sph_blocks_p, a.sph_blocks.size()))) return rc;
   ctx->accel_prepared = false;
@@ -433,7 +449,9 @@ void esc_context_destroy(esc_context *ctx) {
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
                   ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_order,
-                  ctx->d_bvh_tri_blocks_p, ctx->d_bvh_sph_blocks_p};
+                  ctx->d_bvh_tri_blocks_p, ctx->d_bvh_sph_blocks_p,
+                  ctx->d_tri_boxes, ctx->d_sph_boxes, ctx->d_bin_hdr, ctx->d_bin_tri_ids,
+                  ctx->d_bin_sph_ids};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -664,6 +682,33 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
                             ctx->d_bvh_tri_order, ctx->accel_info.tri_root, 0};
     p.bvh_sph = esc::BvhRef{ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_blocks_p,
                             ctx->d_bvh_sph_order, ctx->accel_info.sph_root, 0};
+    // screen-space bins for the primary pass: rebuilt every frame on the stream (they depend on
+    // the camera), sized for the image
+    const char *no_bins = std::getenv("ESC_BVH_BINS");
+    if (!(no_bins && std::strcmp(no_bins, "0") == 0)) {
+      const int tiles_x = (W + 31) / 32, groups_y = (H + esc::kTileH - 1) / esc::kTileH;
+      const size_t n_bins = (size_t)tiles_x * groups_y;
+      if (tiles_x != ctx->bin_tiles_x || groups_y != ctx->bin_groups_y) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int rc;
+        if ((rc = alloc_dev(ctx->d_bin_hdr, esc::kBinHdrInts + 2 * n_bins))) return rc;
+        if ((rc = alloc_dev(ctx->d_bin_tri_ids, n_bins * esc::kBinCap))) return rc;
+        if ((rc = alloc_dev(ctx->d_bin_sph_ids, n_bins * esc::kBinCap))) return rc;
+        // ids start as zeros: a slot past a bin's count must always name a valid primitive
+        HIP_TRY(hipMemsetAsync(ctx->d_bin_tri_ids, 0, n_bins * esc::kBinCap * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_bin_sph_ids, 0, n_bins * esc::kBinCap * 4, ctx->stream));
+        ctx->bin_tiles_x = tiles_x;
+        ctx->bin_groups_y = groups_y;
+      }
+      p.bins = esc::BinGrid{ctx->d_bin_hdr, ctx->d_bin_tri_ids, ctx->d_bin_sph_ids, tiles_x,
+                            groups_y};
+      HIP_TRY(hipMemsetAsync(ctx->d_bin_hdr, 0, (esc::kBinHdrInts + 2 * n_bins) * 4, ctx->stream));
+      int e = esc_launch_bin_primary(&p, ctx->d_tri_boxes, ctx->d_sph_boxes, ctx->stream);
+      if (e) {
+        set_error(std::string("k_bin_primary launch: ") + hipGetErrorString((hipError_t)e));
+        return ESC_ERR_HIP;
+      }
+    }
     stage = 3;
     px = 1; // a wave walks the tree with its 64 rays
   }

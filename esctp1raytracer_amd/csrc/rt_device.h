@@ -128,6 +128,27 @@ struct BvhRef {
   int32_t pad;
 };
 
+// Screen-space bins for PRIMARY rays under ESC_STAGE_BVH.  All primary rays leave one point, so
+// "which primitives can the rays of this 32 x 8 pixel tile meet" is a projection: k_bin_primary
+// projects every primitive's padded box (the same boxes the tree is built from) onto the image
+// plane and appends the primitive to the bins its footprint overlaps.  k_primary<BVH> then tests
+// just its bin with the exact tests.  A bin that overflows, or a band whose tiles do not sit on
+// 8-row image boundaries, falls back to the tree walk.  Primitives that straddle the camera
+// plane, or cover very many bins, go to a short "global" list every tile tests.
+constexpr int kBinCap = 32;      // ids per bin and primitive kind
+constexpr int kBinGlobalCap = 16; // ids of the global lists
+constexpr int kBinHdrInts = 64;  // [0] n global triangles, [1] n global spheres,
+                                 // [2, 2+16) global triangle ids, [18, 34) global sphere ids
+struct BinGrid {
+  int32_t *hdr;     // kBinHdrInts, then counts[n_bins][2] (triangles, spheres): zeroed per frame
+  int32_t *tri_ids; // [n_bins][kBinCap]
+  int32_t *sph_ids; // [n_bins][kBinCap]
+  int32_t tiles_x, groups_y; // bins = 32-pixel columns x 8-row groups of IMAGE rows
+};
+struct PrimBoxDev {
+  float lo[3], hi[3];
+};
+
 struct RenderParams {
   // camera.h:36-39
   float origin[3];
@@ -157,6 +178,7 @@ struct RenderParams {
   unsigned long long *counters;
   HitRec *hits;                 // band-local, n_local_rows * W records (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only
+  BinGrid bins;                 // ESC_STAGE_BVH only; hdr == nullptr: no bins, walk the tree
 };
 
 // pixel tile of one 256-thread workgroup: 2 x 2 waves, each wave (16*PX) x 4 pixels, so the

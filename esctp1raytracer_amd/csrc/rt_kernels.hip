@@ -1327,6 +1327,136 @@ DEVINL void bvh_trace(const RenderParams &p, f3 o, f3 d, RaySt &s, bool alive, i
 }
 
 // ---------------------------------------------------------------------------------------
+// screen-space bins for primary rays (rt_device.h BinGrid)
+// ---------------------------------------------------------------------------------------
+
+// One WAVE per primitive: lanes 0..7 project the eight corners of its padded box, shuffles
+// reduce them to a pixel rectangle, then the 64 lanes append the primitive to the bins of that
+// rectangle side by side (an append is an atomic whose result is needed, so one thread doing
+// them in turn is latency bound).  Projection in double: a world point X lies on the primary ray
+// of image-plane coordinates (s,t) iff X - o = l * (A + s*hor + t*ver), A = llc - o, l > 0
+// (camera.h:31-34), so (l*s, l*t, l) = M^-1 (X - o) with M = [hor ver A].  The rays that meet a
+// convex box lying wholly in front of the camera plane are exactly those through the convex hull
+// of its projected corners, which the pixel bounding box (grown by one pixel for the fp32
+// rounding of main.cpp:709-713) contains.
+constexpr int kBinMaxSpan = 2048; // bins one primitive may be appended to before it goes global
+__global__ void __launch_bounds__(256)
+k_bin_primary(const RenderParams p, const PrimBoxDev *__restrict__ tri_boxes,
+              const PrimBoxDev *__restrict__ sph_boxes) {
+  const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6); // primitive of this wave
+  const int lane = (int)(threadIdx.x & 63u);
+  if (i >= p.n_tri + p.n_sph) return;
+  const bool is_sph = i >= p.n_tri;
+  const int id = is_sph ? i - p.n_tri : i;
+  const PrimBoxDev B = is_sph ? sph_boxes[id] : tri_boxes[id];
+  const BinGrid g = p.bins;
+
+  const double o[3] = {p.origin[0], p.origin[1], p.origin[2]};
+  const double a[3] = {p.horizontal[0], p.horizontal[1], p.horizontal[2]};
+  const double b[3] = {p.vertical[0], p.vertical[1], p.vertical[2]};
+  const double c[3] = {(double)p.llc[0] - o[0], (double)p.llc[1] - o[1], (double)p.llc[2] - o[2]};
+  const double bxc[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
+  const double cxa[3] = {c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]};
+  const double axb[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+  const double det = a[0] * bxc[0] + a[1] * bxc[1] + a[2] * bxc[2];
+  const double inv_det = 1.0 / det;
+
+  const int k = lane & 7; // corner (lanes >= 8 repeat them: harmless for min/max/any)
+  const double q[3] = {(double)((k & 1) ? B.hi[0] : B.lo[0]) - o[0],
+                       (double)((k & 2) ? B.hi[1] : B.lo[1]) - o[1],
+                       (double)((k & 4) ? B.hi[2] : B.lo[2]) - o[2]};
+  const double ls = (bxc[0] * q[0] + bxc[1] * q[1] + bxc[2] * q[2]) * inv_det;
+  const double lt = (cxa[0] * q[0] + cxa[1] * q[1] + cxa[2] * q[2]) * inv_det;
+  const double l = (axb[0] * q[0] + axb[1] * q[1] + axb[2] * q[2]) * inv_det;
+  const double qm = fmax(fabs(q[0]), fmax(fabs(q[1]), fabs(q[2])));
+  const bool front = l > 1e-6 * (1.0 + qm);
+  const unsigned long long fm = __builtin_amdgcn_ballot_w64(front) & 0xFFull;
+  if (fm == 0) return; // wholly behind the camera plane: no primary ray can reach it
+  bool global = fm != 0xFFull; // straddles the camera plane
+  int tx0 = 0, tx1 = -1, gy0 = 0, gy1 = -1;
+  if (!global) {
+    const double wp = ls / l * (double)(p.W - 1), hp = lt / l * (double)(p.H - 1);
+    double wmin = wp, wmax = wp, hmin = hp, hmax = hp;
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) { // butterfly over the 8 corners
+      wmin = fmin(wmin, __shfl_xor(wmin, off));
+      wmax = fmax(wmax, __shfl_xor(wmax, off));
+      hmin = fmin(hmin, __shfl_xor(hmin, off));
+      hmax = fmax(hmax, __shfl_xor(hmax, off));
+    }
+    const double big = 1e9;
+    tx0 = (int)floor(fmax(-big, fmin(big, (wmin - 1.0) / 32.0)));
+    tx1 = (int)floor(fmax(-big, fmin(big, (wmax + 1.0) / 32.0)));
+    gy0 = (int)floor(fmax(-big, fmin(big, (hmin - 1.0) / (double)kTileH)));
+    gy1 = (int)floor(fmax(-big, fmin(big, (hmax + 1.0) / (double)kTileH)));
+    tx0 = max(tx0, 0);
+    gy0 = max(gy0, 0);
+    tx1 = min(tx1, g.tiles_x - 1);
+    gy1 = min(gy1, g.groups_y - 1);
+    if (tx0 > tx1 || gy0 > gy1) return; // off screen
+    global = (long long)(tx1 - tx0 + 1) * (gy1 - gy0 + 1) > kBinMaxSpan;
+  }
+  if (global) {
+    if (lane == 0) {
+      const int slot = atomicAdd(&g.hdr[is_sph ? 1 : 0], 1);
+      if (slot < kBinGlobalCap) g.hdr[(is_sph ? 2 + kBinGlobalCap : 2) + slot] = id;
+    }
+    return;
+  }
+  int32_t *counts = g.hdr + kBinHdrInts;
+  int32_t *ids = is_sph ? g.sph_ids : g.tri_ids;
+  const int nx = tx1 - tx0 + 1, n = nx * (gy1 - gy0 + 1);
+  for (int j = lane; j < n; j += 64) {
+    const int bin = (gy0 + j / nx) * g.tiles_x + tx0 + j % nx;
+    const int slot = atomicAdd(&counts[2 * bin + (is_sph ? 1 : 0)], 1);
+    if (slot < kBinCap) ids[(size_t)bin * kBinCap + slot] = id;
+  }
+}
+
+// Closest hit of a tile's primary rays from its bin.  Returns false (nothing tested) when the bin
+// cannot be used; the caller then walks the tree.  Slots past a bin's count hold ids of earlier
+// frames or zeros -- always valid primitives of the current scene, and testing an extra
+// primitive cannot change a closest hit -- so lists are read in whole batches.
+DEVINL bool bin_trace(const RenderParams &p, int tx, int h_tile, f3 d, RaySt &s, bool alive) {
+  const BinGrid g = p.bins;
+  if (g.hdr == nullptr || (h_tile % kTileH) != 0) return false;
+  const int gy = h_tile / kTileH;
+  if (tx >= g.tiles_x || gy >= g.groups_y) return false;
+  typedef const int32_t __attribute__((address_space(4))) *CI;
+  const CI hdr = (CI)(uintptr_t)g.hdr;
+  const int bin = gy * g.tiles_x + tx;
+  const int n_gt = hdr[0], n_gs = hdr[1];
+  const int n_t = hdr[kBinHdrInts + 2 * bin], n_s = hdr[kBinHdrInts + 2 * bin + 1];
+  if (n_gt > kBinGlobalCap || n_gs > kBinGlobalCap || n_t > kBinCap || n_s > kBinCap) return false;
+  const SmemFetch<DevTriP> tris{p.tri_p};
+  const SmemFetch<DevSphP> sphs{p.sph_p};
+  const uint32_t nt = (uint32_t)p.n_tri;
+  auto tri_list = [&](CI ids, int n) {
+    for (int k = 0; k < n; ++k) {
+      const int id = ids[k];
+      const DevTriP T[1] = {tris(id)};
+      test_tris_primary<0, 1>(T, [&](int) { return (uint32_t)id; }, d, s, alive);
+    }
+  };
+  auto sph_list = [&](CI ids, int n) { // n rounded up to whole batches of 4 by the caller
+    for (int k = 0; k < n; k += 4) {
+      const int i0 = ids[k], i1 = ids[k + 1], i2 = ids[k + 2], i3 = ids[k + 3];
+      const DevSphP S[4] = {sphs(i0), sphs(i1), sphs(i2), sphs(i3)};
+      test_sphs_primary<0, 4>(
+          S, [&](int i) { return nt + (uint32_t)(i == 0 ? i0 : i == 1 ? i1 : i == 2 ? i2 : i3); }, d,
+          s, alive);
+    }
+  };
+  tri_list(hdr + 2, n_gt);
+  tri_list((CI)(uintptr_t)(g.tri_ids + (size_t)bin * kBinCap), n_t);
+  if (p.n_sph > 0) {
+    sph_list(hdr + 2 + kBinGlobalCap, (n_gs + 3) & ~3);
+    sph_list((CI)(uintptr_t)(g.sph_ids + (size_t)bin * kBinCap), (n_s + 3) & ~3);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
 // The frame = two kernels on the same stream.
 //
 //   k_primary<STAGE, V, NV>  camera.h:31-34 get_ray + main.cpp:722 closest hit over every
@@ -1412,8 +1542,10 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     s.v = 0.f;
     s.key = kNoKey;
     int n_visits = 0, n_tests = 0, n_swept = 0;
-    bvh_trace<0, true>(p, mk(p.origin[0], p.origin[1], p.origin[2]), dir[0], s, row_ok && w[0] < p.W,
-                 n_visits, n_tests, n_swept);
+    const bool alive = row_ok && w[0] < p.W;
+    if (!bin_trace(p, T.w0 / 32, T.h_tile, dir[0], s, alive))
+      bvh_trace<0, true>(p, mk(p.origin[0], p.origin[1], p.origin[2]), dir[0], s, alive, n_visits,
+                         n_tests, n_swept);
     hit[0].t = s.tmax;
     hit[0].v = s.v;
     hit[0].idx = (int32_t)s.key; // kNoKey -> -1
@@ -1815,6 +1947,15 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
                      tri_p, p->n_tri, p->sph, sph_p, sph2_p, p->n_sph, p->origin[0], p->origin[1],
                      p->origin[2]);
+  return (int)hipGetLastError();
+}
+
+extern "C" int esc_launch_bin_primary(const esc::RenderParams *p, const esc::PrimBoxDev *tri_boxes,
+                                      const esc::PrimBoxDev *sph_boxes, hipStream_t stream) {
+  const int n = p->n_tri + p->n_sph;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(esc::k_bin_primary, dim3((n + 3) / 4), dim3(256), 0, stream, *p, tri_boxes,
+                     sph_boxes); // one wave per primitive
   return (int)hipGetLastError();
 }
 

@@ -498,3 +498,60 @@ def test_bvh_full_size_equals_brute_force(esc, renderer, config, W, H):
     for k in ("primary_rays", "hit_pixels", "shadow_rays"):
         assert ca[k] == cb[k]
     assert float(a.sum().item()) > 0
+
+
+@pytest.mark.parametrize("eye,look", [((0.0, 2.5, -9.0), (3.0, 2.0, -15.0)),   # inside the cloud
+                                      ((0.0, 2.5, -9.0), (0.0, 2.5, 5.0)),     # looking back out
+                                      ((7.9, 0.6, -2.1), (-8.0, 4.0, -20.0)),  # from a corner
+                                      ((0.0, 30.0, -10.0), (0.0, 0.0, -10.01)),  # straight down
+                                      ((0.0, 3.0, 40.0), (0.0, 3.0, 80.0))])   # everything behind
+def test_bvh_bins_awkward_cameras(esc, renderer, eye, look):
+    """screen-space bins of the primary pass: primitives behind the camera, straddling the camera
+    plane (global list), off screen; every case against the oracle"""
+    sc, d = synthetic_dict(esc, "c3", 500)
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, 224, 136)
+    gpu = renderer.render(cam, 224, 136, stage=esc.ESC_STAGE_BVH)
+    ref = ol.oracle_render(d, eye, look, 224, 136, threads=8)
+    assert_bit_equal(gpu, ref, f"bvh bins/eye{eye}")
+
+
+def test_bvh_bin_overflow_falls_back_to_the_tree(esc, renderer):
+    """> 32 spheres behind one another in one tile, and > 16 spheres around the camera: the bin
+    (or the global list) overflows and those tiles (or all) walk the tree instead"""
+    rng = np.random.default_rng(3)
+    n = 90
+    line = np.stack([np.full(n, 0.02), np.full(n, 1.0), -np.linspace(2.0, 40.0, n),
+                     np.linspace(0.05, 0.6, n)], axis=1)
+    ang = np.linspace(0.0, 2 * np.pi, 24, endpoint=False)  # a ring in the camera plane z = 3
+    around = np.stack([3.0 * np.cos(ang), 1.0 + 3.0 * np.sin(ang), np.full(24, 3.0),
+                       np.full(24, 0.8)], axis=1)
+    d = ol.load_dump("one")
+    for sph in (line, np.concatenate([line, around])):
+        mats = np.stack([ol.material13(ka=c, kd=c) for c in rng.uniform(0.2, 0.9, (len(sph), 3))])
+        d2 = ol.scene_dict(d["geometry"], sph.astype(np.float32), mats)
+        gpu, u8, ref = render_both(esc, renderer, d2, (0, 1, 3), (0, 1, 0), 160, 96,
+                                   stage=esc.ESC_STAGE_BVH)
+        assert_bit_equal(gpu, ref, f"bvh bins overflow/{len(sph)}")
+        assert ref.sum() > 0
+
+
+def test_bvh_unaligned_band_and_bins_off(esc, renderer, monkeypatch):
+    """a band that starts off the 8-row grid cannot use the bins (tree walk), and ESC_BVH_BINS=0
+    switches them off altogether: same pixels either way"""
+    import torch
+    sc, d = synthetic_dict(esc, "c3", 300)
+    eye, look = esc.synthetic_view()
+    W, H = 160, 96
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    full = renderer.render(cam, W, H, stage=esc.ESC_STAGE_BVH)
+    ref = ol.oracle_render(d, eye, look, W, H, threads=8)
+    assert_bit_equal(full, ref, "bvh/full")
+    band = torch.zeros(40 * W * 3, dtype=torch.float32, device="cuda:0")
+    renderer.render_rows(cam, W, H, 13, 53, out_f32=band, stage=esc.ESC_STAGE_BVH)
+    renderer.synchronize()
+    assert_bit_equal(band.cpu().numpy().reshape(40, W, 3), ref[13:53], "bvh/unaligned band")
+    monkeypatch.setenv("ESC_BVH_BINS", "0")
+    nobins = renderer.render(cam, W, H, stage=esc.ESC_STAGE_BVH)
+    assert_bit_equal(nobins, ref, "bvh/bins off")
