@@ -27,6 +27,10 @@ extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_
                                       float ox, float oy, float oz, hipStream_t stream);
 extern "C" int esc_launch_bin_primary(const esc::RenderParams *p, const esc::PrimBoxDev *tri_boxes,
                                       const esc::PrimBoxDev *sph_boxes, hipStream_t stream);
+extern "C" int esc_launch_bin_light(const esc::LightBins *g, const float *light_points,
+                                    const esc::PrimBoxDev *tri_boxes, int n_tri,
+                                    const esc::PrimBoxDev *sph_boxes, int n_sph,
+                                    hipStream_t stream);
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px,
                                  hipStream_t stream);
 extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
@@ -84,6 +88,8 @@ struct esc_context {
   esc::PrimBoxDev *d_tri_boxes = nullptr, *d_sph_boxes = nullptr;
   int32_t *d_bin_hdr = nullptr, *d_bin_tri_ids = nullptr, *d_bin_sph_ids = nullptr;
   int bin_tiles_x = 0, bin_groups_y = 0;
+  // light-space bins of the shadow pass (rt_device.h LightBins), built with the tree
+  esc::LightBins lbins{};
   bool accel_valid = false;
   esc::OriginBounds accel_ob{};
   esc_accel_info accel_info{};
@@ -381,6 +387,34 @@ int build_accel_device(esc_context *ctx, const float origin[3]) {
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // tb / sb die here
   }
   ctx->bin_tiles_x = ctx->bin_groups_y = 0; // bins hold ids of the old scene: start over
+  {
+    // cube maps around the light sample points (they belong to the scene, not to the camera)
+    const int n_pts = (int)(ctx->h_light_points.size() / 4);
+    const size_t n_prims = ctx->h_tri.size() + ctx->h_sph.size();
+    esc::LightBins &g = ctx->lbins;
+    g.n_points = 0;
+    // measured: with ~100k triangles a cell holds more candidates than a tree walk visits
+    // (c5: 15.8 vs 6.5 tests per shadow ray, frame 1.34 vs 1.29 ms), so big scenes keep the walk
+    if (n_pts >= 1 && n_pts <= esc::kLightGridsMax && n_prims > 0 && n_prims <= 32768) {
+      g.R = 64;
+      const size_t n_cells = (size_t)n_pts * 6 * g.R * g.R;
+      if ((rc = alloc_dev(g.face_hdr, (size_t)n_pts * 6 * esc::kBinHdrInts))) return rc;
+      if ((rc = alloc_dev(g.counts, 2 * n_cells))) return rc;
+      if ((rc = alloc_dev(g.tri_ids, n_cells * esc::kBinCap))) return rc;
+      if ((rc = alloc_dev(g.sph_ids, n_cells * esc::kBinCap))) return rc;
+      HIP_TRY(hipMemsetAsync(g.face_hdr, 0, (size_t)n_pts * 6 * esc::kBinHdrInts * 4, ctx->stream));
+      HIP_TRY(hipMemsetAsync(g.counts, 0, 2 * n_cells * 4, ctx->stream));
+      HIP_TRY(hipMemsetAsync(g.tri_ids, 0, n_cells * esc::kBinCap * 4, ctx->stream));
+      HIP_TRY(hipMemsetAsync(g.sph_ids, 0, n_cells * esc::kBinCap * 4, ctx->stream));
+      g.n_points = n_pts;
+      int e = esc_launch_bin_light(&g, ctx->d_light_points, ctx->d_tri_boxes, (int)ctx->h_tri.size(),
+                                   ctx->d_sph_boxes, (int)ctx->h_sph.size(), ctx->stream);
+      if (e) {
+        set_error(std::string("k_bin_light launch: ") + hipGetErrorString((hipError_t)e));
+        return ESC_ERR_HIP;
+      }
+    }
+  }
   if ((rc = alloc_dev(ctx->d_bvh_tri_blocks_p, a.tri_blocks.size()))) return rc;
   if ((rc = alloc_dev(ctx->d_bvh_sph_blocks_p, a.sph_blocks.size()))) return rc;
   ctx->accel_prepared = false;
@@ -451,7 +485,8 @@ void esc_context_destroy(esc_context *ctx) {
                   ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_order,
                   ctx->d_bvh_tri_blocks_p, ctx->d_bvh_sph_blocks_p,
                   ctx->d_tri_boxes, ctx->d_sph_boxes, ctx->d_bin_hdr, ctx->d_bin_tri_ids,
-                  ctx->d_bin_sph_ids};
+                  ctx->d_bin_sph_ids, ctx->lbins.face_hdr, ctx->lbins.counts, ctx->lbins.tri_ids,
+                  ctx->lbins.sph_ids};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -702,6 +737,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       }
       p.bins = esc::BinGrid{ctx->d_bin_hdr, ctx->d_bin_tri_ids, ctx->d_bin_sph_ids, tiles_x,
                             groups_y};
+      p.lbins = ctx->lbins;
       HIP_TRY(hipMemsetAsync(ctx->d_bin_hdr, 0, (esc::kBinHdrInts + 2 * n_bins) * 4, ctx->stream));
       int e = esc_launch_bin_primary(&p, ctx->d_tri_boxes, ctx->d_sph_boxes, ctx->stream);
       if (e) {

@@ -149,6 +149,24 @@ struct PrimBoxDev {
   float lo[3], hi[3];
 };
 
+// The same idea for SHADOW rays: every shadow ray towards one light sample point L (quirk S2
+// makes the sample a fixed point per light face) lies on a line through L, so an occluder must be
+// seen from L in the direction of the shaded point.  Directions from L are binned on a cube map
+// (6 faces x R x R cells); k_bin_light projects every padded primitive box onto it once per scene
+// (lights do not move with the camera).  A shadow ray looks up the cell of (hit point - L) and
+// tests that cell's primitives with the exact test.  Per face, primitives that straddle the
+// face's plane through L go to a short face-global list; overflowing cells / lists make the rays
+// that land there walk the tree instead.
+constexpr int kLightGridsMax = 4; // light sample points that get a cube map (more: tree walk only)
+struct LightBins {
+  int32_t *face_hdr; // [n_points*6][kBinHdrInts]  (layout of BinGrid::hdr)
+  int32_t *counts;   // [n_points*6*R*R][2]
+  int32_t *tri_ids;  // [n_cells][kBinCap]
+  int32_t *sph_ids;  // [n_cells][kBinCap]
+  int32_t n_points;  // 0: no light bins
+  int32_t R;
+};
+
 struct RenderParams {
   // camera.h:36-39
   float origin[3];
@@ -179,6 +197,7 @@ struct RenderParams {
   HitRec *hits;                 // band-local, n_local_rows * W records (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only
   BinGrid bins;                 // ESC_STAGE_BVH only; hdr == nullptr: no bins, walk the tree
+  LightBins lbins;              // ESC_STAGE_BVH only; n_points == 0: none
 };
 
 // pixel tile of one 256-thread workgroup: 2 x 2 waves, each wave (16*PX) x 4 pixels, so the

@@ -1457,6 +1457,169 @@ DEVINL bool bin_trace(const RenderParams &p, int tx, int h_tile, f3 d, RaySt &s,
 }
 
 // ---------------------------------------------------------------------------------------
+// light-space bins for shadow rays (rt_device.h LightBins)
+// ---------------------------------------------------------------------------------------
+
+// cube-map face of a direction v: 2*axis + (negative ? 1 : 0), axis = the largest |component|
+// (lowest index on ties); (u, w) = the other two components over |v[axis]|, in axis order
+DEVINL int cube_face(f3 v, float &u, float &w) {
+  const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z);
+  int m = 0;
+  float dm = ax;
+  if (ay > dm) { m = 1; dm = ay; }
+  if (az > dm) { m = 2; dm = az; }
+  const float vm = (m == 0) ? v.x : (m == 1) ? v.y : v.z;
+  const float va = (m == 0) ? v.y : v.x;
+  const float vb = (m == 2) ? v.y : v.z;
+  u = va / dm;
+  w = vb / dm;
+  return 2 * m + ((vm < 0.f) ? 1 : 0);
+}
+
+// One wave per primitive, once per scene: for every light point and cube face, lanes 0..7 project
+// the eight corners of the padded box (double), the wave reduces them to a cell rectangle (grown
+// by 1e-5 in face coordinates for the fp32 lookup in k_shade) and appends side by side.
+__global__ void __launch_bounds__(256)
+k_bin_light(const LightBins g, const float *__restrict__ light_points,
+            const PrimBoxDev *__restrict__ tri_boxes, int n_tri,
+            const PrimBoxDev *__restrict__ sph_boxes, int n_sph) {
+  const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63u);
+  if (i >= n_tri + n_sph) return;
+  const bool is_sph = i >= n_tri;
+  const int id = is_sph ? i - n_tri : i;
+  const PrimBoxDev B = is_sph ? sph_boxes[id] : tri_boxes[id];
+  const int k = lane & 7;
+  const int R = g.R;
+  for (int pt = 0; pt < g.n_points; ++pt) {
+    const double L[3] = {light_points[4 * pt], light_points[4 * pt + 1], light_points[4 * pt + 2]};
+    const double q[3] = {(double)((k & 1) ? B.hi[0] : B.lo[0]) - L[0],
+                         (double)((k & 2) ? B.hi[1] : B.lo[1]) - L[1],
+                         (double)((k & 4) ? B.hi[2] : B.lo[2]) - L[2]};
+    const double qm = fmax(fabs(q[0]), fmax(fabs(q[1]), fabs(q[2])));
+    for (int face = 0; face < 6; ++face) {
+      const int m = face >> 1;
+      const double sg = (face & 1) ? -1.0 : 1.0;
+      const double depth = sg * q[m];
+      const double qa = (m == 0) ? q[1] : q[0], qb = (m == 2) ? q[1] : q[2];
+      const bool front = depth > 1e-9 * (1.0 + qm);
+      const unsigned long long fm = __builtin_amdgcn_ballot_w64(front) & 0xFFull;
+      if (fm == 0) continue; // wholly behind this face's plane through L
+      int32_t *hdr = g.face_hdr + (size_t)(pt * 6 + face) * kBinHdrInts;
+      bool global = fm != 0xFFull;
+      int cu0 = 0, cu1 = -1, cw0 = 0, cw1 = -1;
+      if (!global) {
+        const double u = qa / depth, w = qb / depth;
+        double umin = u, umax = u, wmin = w, wmax = w;
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+          umin = fmin(umin, __shfl_xor(umin, off));
+          umax = fmax(umax, __shfl_xor(umax, off));
+          wmin = fmin(wmin, __shfl_xor(wmin, off));
+          wmax = fmax(wmax, __shfl_xor(wmax, off));
+        }
+        if (umin > 1.0 + 1e-5 || umax < -1.0 - 1e-5 || wmin > 1.0 + 1e-5 || wmax < -1.0 - 1e-5)
+          continue; // seen from L through other faces only
+        const double h = 0.5 * (double)R;
+        cu0 = max(0, (int)floor((fmax(umin, -1.0) - 1e-5 + 1.0) * h));
+        cu1 = min(R - 1, (int)floor((fmin(umax, 1.0) + 1e-5 + 1.0) * h));
+        cw0 = max(0, (int)floor((fmax(wmin, -1.0) - 1e-5 + 1.0) * h));
+        cw1 = min(R - 1, (int)floor((fmin(wmax, 1.0) + 1e-5 + 1.0) * h));
+        global = (long long)(cu1 - cu0 + 1) * (cw1 - cw0 + 1) > kBinMaxSpan;
+      }
+      if (global) {
+        if (lane == 0) {
+          const int slot = atomicAdd(&hdr[is_sph ? 1 : 0], 1);
+          if (slot < kBinGlobalCap) hdr[(is_sph ? 2 + kBinGlobalCap : 2) + slot] = id;
+        }
+        continue;
+      }
+      int32_t *ids = is_sph ? g.sph_ids : g.tri_ids;
+      const size_t cell0 = (size_t)(pt * 6 + face) * R * R;
+      const int nx = cu1 - cu0 + 1, n = nx * (cw1 - cw0 + 1);
+      for (int j = lane; j < n; j += 64) {
+        const size_t cell = cell0 + (size_t)(cw0 + j / nx) * R + cu0 + j % nx;
+        const int slot = atomicAdd(&g.counts[2 * cell + (is_sph ? 1 : 0)], 1);
+        if (slot < kBinCap) ids[cell * kBinCap + slot] = id;
+      }
+    }
+  }
+}
+
+// cell of the shadow ray that ends in light point `pt` and starts at `ro`, or -1
+DEVINL int light_cell(const LightBins &g, int pt, f3 Lp, f3 ro) {
+  float u, w;
+  const int face = cube_face(ro - Lp, u, w);
+  const float h = 0.5f * (float)g.R;
+  const int cu = min(g.R - 1, max(0, (int)floorf((u + 1.f) * h)));
+  const int cw = min(g.R - 1, max(0, (int)floorf((w + 1.f) * h)));
+  return ((pt * 6 + face) * g.R + cw) * g.R + cu;
+}
+
+// Shadow rays of a wave through the light bins.  `cell` < 0: this lane has no ray for the bins.
+// The wave serves one distinct cell at a time (rays of neighbouring pixels mostly share theirs).
+// Lanes whose cell or face list overflowed are returned in the mask: they must walk the tree.
+template <int MODE>
+DEVINL unsigned long long light_bins_trace(const RenderParams &p, int cell, f3 o, f3 d, RaySt &s,
+                                           int &n_tests, int &n_swept) {
+  typedef unsigned long long mask_t;
+  typedef const int32_t __attribute__((address_space(4))) *CI;
+  const LightBins g = p.lbins;
+  const SmemFetch<DevTri> tris{p.tri};
+  const SmemFetch<DevSph> sphs{p.sph};
+  const uint32_t nt = (uint32_t)p.n_tri;
+  const int cells_per_face = g.R * g.R;
+  mask_t todo = __builtin_amdgcn_ballot_w64(cell >= 0);
+  mask_t fallback = 0;
+  while (todo != 0) {
+    const int lead = __builtin_ctzll(todo);
+    const int c = __builtin_amdgcn_readlane(cell, lead);
+    const mask_t same = __builtin_amdgcn_ballot_w64(cell == c) & todo;
+    todo &= ~same;
+    const bool mine = cell == c;
+    const CI hdr = (CI)(uintptr_t)(g.face_hdr + (size_t)(c / cells_per_face) * kBinHdrInts);
+    const CI cnt = (CI)(uintptr_t)(g.counts + 2 * (size_t)c);
+    const int n_gt = hdr[0], n_gs = hdr[1], n_t = cnt[0], n_s = cnt[1];
+    if (n_gt > kBinGlobalCap || n_gs > kBinGlobalCap || n_t > kBinCap || n_s > kBinCap) {
+      fallback |= same;
+      continue;
+    }
+    auto looking = [&]() { return (MODE == 1) ? (mine && s.key == kNoKey) : mine; };
+    auto tri_list = [&](CI ids, int n) {
+      for (int k = 0; k < n; ++k) {
+        const bool act = looking();
+        if (MODE == 1 && __builtin_amdgcn_ballot_w64(act) == 0) return;
+        const int id = ids[k];
+        const DevTri T[1] = {tris(id)};
+        test_tris_general<MODE, 1>(T, [&](int) { return (uint32_t)id; }, o, d, s, act);
+        n_tests += act ? 1 : 0;
+        n_swept += 1;
+      }
+    };
+    auto sph_list = [&](CI ids, int n) { // whole batches of 4: spare slots name valid spheres
+      for (int k = 0; k < n; k += 4) {
+        const bool act = looking();
+        if (MODE == 1 && __builtin_amdgcn_ballot_w64(act) == 0) return;
+        const int i0 = ids[k], i1 = ids[k + 1], i2 = ids[k + 2], i3 = ids[k + 3];
+        const DevSph S[4] = {sphs(i0), sphs(i1), sphs(i2), sphs(i3)};
+        test_sphs_general<MODE, 4>(
+            S, [&](int i) { return nt + (uint32_t)(i == 0 ? i0 : i == 1 ? i1 : i == 2 ? i2 : i3); },
+            o, d, s, act);
+        n_tests += act ? 4 : 0;
+        n_swept += 4;
+      }
+    };
+    tri_list(hdr + 2, n_gt);
+    tri_list((CI)(uintptr_t)(g.tri_ids + (size_t)c * kBinCap), n_t);
+    if (p.n_sph > 0) {
+      sph_list(hdr + 2 + kBinGlobalCap, (n_gs + 3) & ~3);
+      sph_list((CI)(uintptr_t)(g.sph_ids + (size_t)c * kBinCap), (n_s + 3) & ~3);
+    }
+  }
+  return fallback;
+}
+
+// ---------------------------------------------------------------------------------------
 // The frame = two kernels on the same stream.
 //
 //   k_primary<STAGE, V, NV>  camera.h:31-34 get_ray + main.cpp:722 closest hit over every
@@ -1666,6 +1829,8 @@ __global__ void __launch_bounds__(256, ESC_SHADE_WAVES) k_shade(const RenderPara
     const DevLight Lt = p.lights[li];
     Any a[1];
     f3 ro = N, rL = N; // shadow-ray origin (main.cpp:757 `hit`) and unit direction
+    f3 lP = N;         // the light sample point and its index (light bins, ESC_STAGE_BVH)
+    int lpt = 0;
     a[0].tb = 0.f;
     a[0].tocc = 0.f;
     a[0].kocc = -1;
@@ -1677,6 +1842,8 @@ __global__ void __launch_bounds__(256, ESC_SHADE_WAVES) k_shade(const RenderPara
                               : face_hash(p.seed, (uint32_t)(h * p.W + w), (uint32_t)li,
                                           (uint32_t)Lt.n_faces);
       const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
+      lP = P;
+      lpt = Lt.first_point + (int)face;
       // the primary direction is recomputed here (same ops, same bits) rather than kept in
       // registers across the any-hit loops of the previous light
       const f3 dir = (STAGE == STAGE_BVH) ? dir_kept : primary_dir(p, w, h);
@@ -1698,10 +1865,21 @@ __global__ void __launch_bounds__(256, ESC_SHADE_WAVES) k_shade(const RenderPara
         int n_visits = 0, n_tests = 0;
         // the occluder's t2 is only ever read by the NEXT light (quirk S3): the last light may
         // stop at any occluder, the others need the first one in primitive order
-        if (li + 1 < p.n_lights)
-          bvh_trace<2, false>(p, ro, rL, s, a[0].tb > 0.f, n_visits, n_tests, n_swept);
+        const bool need_first = li + 1 < p.n_lights;
+        const bool ray = a[0].tb > 0.f;
+        bool walk = ray; // rays the light bins cannot serve walk the tree
+        if (p.lbins.n_points > 0) {
+          int cell = -1;
+          if (ray && lpt < p.lbins.n_points) cell = light_cell(p.lbins, lpt, lP, ro);
+          const unsigned long long fb =
+              need_first ? light_bins_trace<2>(p, cell, ro, rL, s, n_tests, n_swept)
+                         : light_bins_trace<1>(p, cell, ro, rL, s, n_tests, n_swept);
+          walk = ray && (cell < 0 || ((fb >> lane) & 1ull) != 0);
+        }
+        if (need_first)
+          bvh_trace<2, false>(p, ro, rL, s, walk, n_visits, n_tests, n_swept);
         else
-          bvh_trace<1, false>(p, ro, rL, s, a[0].tb > 0.f, n_visits, n_tests, n_swept);
+          bvh_trace<1, false>(p, ro, rL, s, walk, n_visits, n_tests, n_swept);
         a[0].kocc = (int32_t)s.key; // kNoKey -> -1
         a[0].tocc = s.thit;
         n_any += (unsigned)n_tests;
@@ -1956,6 +2134,17 @@ extern "C" int esc_launch_bin_primary(const esc::RenderParams *p, const esc::Pri
   if (n <= 0) return 0;
   hipLaunchKernelGGL(esc::k_bin_primary, dim3((n + 3) / 4), dim3(256), 0, stream, *p, tri_boxes,
                      sph_boxes); // one wave per primitive
+  return (int)hipGetLastError();
+}
+
+extern "C" int esc_launch_bin_light(const esc::LightBins *g, const float *light_points,
+                                    const esc::PrimBoxDev *tri_boxes, int n_tri,
+                                    const esc::PrimBoxDev *sph_boxes, int n_sph,
+                                    hipStream_t stream) {
+  const int n = n_tri + n_sph;
+  if (n <= 0 || g->n_points <= 0) return 0;
+  hipLaunchKernelGGL(esc::k_bin_light, dim3((n + 3) / 4), dim3(256), 0, stream, *g, light_points,
+                     tri_boxes, n_tri, sph_boxes, n_sph);
   return (int)hipGetLastError();
 }
 

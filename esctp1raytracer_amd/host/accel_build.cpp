@@ -12,7 +12,9 @@
 //        |disc - (r^2 - dist^2)| <= 18 u |oc|^2 + 2 u r^2,     dist = distance centre <-> ray line
 //    so disc >= 0 implies dist^2 <= r^2 + 18 u M^2 + ..., and the accepted t2 = -b -+ sqrt(disc)
 //    puts o + t2 d within sqrt(r^2 + 28 u M^2) of the centre.  The box is the cube around the
-//    centre with half-width  R = sqrt(r^2 + 32 u M^2) + 8 u M.
+//    centre with half-width  R = sqrt(r^2 + 32 u M^2) + 16 u M  (the linear term also absorbs the
+//    <= 2 u M by which a shadow ray's rounded direction leaves the exact line to its light point,
+//    which the light-space bins are laid out on).
 //
 //  * triangle (ray_triangle.h:7-57, Cramer's rule, numerators in fp32): the numerators
 //    dot(tvec,pvec), dot(dir,qvec) carry an absolute error of ~3 u |tvec| |edge| that does not
@@ -122,7 +124,7 @@ void sphere_boxes(const std::vector<DevSph> &sph, const OriginBounds &ob,
     const double c[3] = {s.cx, s.cy, s.cz};
     const double r2 = std::max(0.0, (double)s.r2);
     const double M = far_corner(ob, c) + std::sqrt(r2);
-    const double R = std::sqrt(r2 * (1.0 + 4 * kU) + 32.0 * kU * M * M) + 8.0 * kU * M;
+    const double R = std::sqrt(r2 * (1.0 + 4 * kU) + 32.0 * kU * M * M) + 16.0 * kU * M;
     for (int a = 0; a < 3; a++) {
       out[i].lo[a] = down(c[a] - R);
       out[i].hi[a] = up(c[a] + R);
