@@ -555,3 +555,31 @@ def test_bvh_unaligned_band_and_bins_off(esc, renderer, monkeypatch):
     monkeypatch.setenv("ESC_BVH_BINS", "0")
     nobins = renderer.render(cam, W, H, stage=esc.ESC_STAGE_BVH)
     assert_bit_equal(nobins, ref, "bvh/bins off")
+
+
+def _spheres_with_lights(esc, light_tris, n=400):
+    """c3's spheres + floor, with the given light triangles (one geometry each) instead of c3's"""
+    sc, d = synthetic_dict(esc, "c3", n)
+    geoms = [g for i, g in enumerate(d["geometry"]) if i not in d["light_sources"]]
+    for tri in light_tris:
+        geoms.append({"vertex": np.array(tri, np.float32), "face_index": np.array([[0, 1, 2]]),
+                      "material": ol.material13(ka=(.78,) * 3, kd=(.78,) * 3, ke=(17, 12, 4))})
+    return ol.scene_dict(geoms, d["spheres"], d["sphere_materials"])
+
+
+@pytest.mark.parametrize("case", ["light inside the cloud", "two lights", "five lights"])
+def test_bvh_light_bins_awkward_lights(esc, renderer, case):
+    """light-space bins of the shadow pass: a light in the middle of the spheres (boxes straddle
+    every cube face: face lists overflow, rays walk the tree), two lights (first-occluder mode
+    through the bins), five light points (more than get a cube map: tree walk only)"""
+    up = [(-0.5, 12, -9.5), (0.0, 12, -10.5), (0.5, 12, -9.5)]
+    mid = [(-0.2, 2.6, -9.8), (0.0, 2.6, -10.2), (0.2, 2.6, -9.8)]
+    side = [(-7.5, 6.0, -3.0), (-7.5, 6.5, -3.5), (-7.0, 6.0, -3.0)]
+    tris = {"light inside the cloud": [mid], "two lights": [up, side],
+            "five lights": [up, side, mid, [(6, 7, -15), (6, 7.5, -15), (6.5, 7, -15)],
+                            [(0, 9, -20), (0.5, 9, -20), (0, 9, -20.5)]]}[case]
+    d = _spheres_with_lights(esc, tris)
+    eye, look = esc.synthetic_view()
+    gpu, u8, ref = render_both(esc, renderer, d, eye, look, 224, 128, stage=esc.ESC_STAGE_BVH)
+    assert_bit_equal(gpu, ref, f"bvh light bins/{case}")
+    assert ref.sum() > 0
