@@ -113,7 +113,7 @@ def accel_leg(esc, r, st, cam, eye, W, H, shadows, steps, warmup, brute_frame, a
     differing = int((buf.view(torch.int32) != brute_frame[:H * W * 3].view(torch.int32)).sum().item())
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return {"stage": "bvh", "value": rays / (ms * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms,
-            "steps": steps, "timing": "HIP events around k_primary<BVH> + k_shade<BVH> per frame",
+            "steps": steps, "timing": "HIP events around the whole frame: memset + k_bin_primary + k_shade<BVH> (closest hit and shading in one kernel)",
             "fp32_values_differing_from_brute_force": differing,
             "identical_to_brute_force": differing == 0,
             "tree": {k: acc[k] for k in ("tri_nodes", "tri_depth", "sph_nodes", "sph_depth")},

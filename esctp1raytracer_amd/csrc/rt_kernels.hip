@@ -1697,22 +1697,7 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   // ---- main.cpp:722 closest hit over every primitive
   V3<V> dv[NV];
   pack3<V, NV>(dir, dv);
-  if constexpr (STAGE == STAGE_BVH) {
-    static_assert(PX == 1, "the tree walk carries one ray per lane");
-    RaySt s;
-    s.tmax = (row_ok && w[0] < p.W) ? FLT_MAX : 0.f; // main.cpp:715
-    s.thit = 0.f;
-    s.v = 0.f;
-    s.key = kNoKey;
-    int n_visits = 0, n_tests = 0, n_swept = 0;
-    const bool alive = row_ok && w[0] < p.W;
-    if (!bin_trace(p, T.w0 / 32, T.h_tile, dir[0], s, alive))
-      bvh_trace<0, true>(p, mk(p.origin[0], p.origin[1], p.origin[2]), dir[0], s, alive, n_visits,
-                         n_tests, n_swept);
-    hit[0].t = s.tmax;
-    hit[0].v = s.v;
-    hit[0].idx = (int32_t)s.key; // kNoKey -> -1
-  } else if (STAGE == STAGE_SMEM) {
+  if (STAGE == STAGE_SMEM) {
     closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dv, hit);
     if constexpr (PX == 2) {
       // multiples of 8 through the hand-scheduled packed body, the tail through the generic one
@@ -1787,14 +1772,28 @@ __global__ void __launch_bounds__(256, ESC_SHADE_WAVES) k_shade(const RenderPara
   hr.v = 0.f;
   hr.idx = -1;
   hr.pad = 0;
-  if (inside) hr = p.hits[(size_t)lr * p.W + w];
-  const bool has_hit = inside && (hr.idx >= 0);
-
-  // the tree walk holds few registers, so its variant keeps the primary direction instead of
-  // recomputing it (two divides, a square root and three more divides each time)
+  // ESC_STAGE_BVH is ONE kernel: the closest hit is found right here (screen bin of this tile,
+  // else the tree walk) instead of being handed over through HBM by k_primary -- its search
+  // holds few registers, so nothing spills, and the primary direction is computed once and kept
+  // (two divides, a square root and three more divides each time otherwise).
   f3 dir_kept = mk(0.f, 0.f, 0.f);
-  if constexpr (STAGE == STAGE_BVH)
-    if (has_hit) dir_kept = primary_dir(p, w, h);
+  if constexpr (STAGE == STAGE_BVH) {
+    if (inside) dir_kept = primary_dir(p, w, h); // camera.h:31-34
+    RaySt s;
+    s.tmax = inside ? FLT_MAX : 0.f; // main.cpp:715
+    s.thit = 0.f;
+    s.v = 0.f;
+    s.key = kNoKey;
+    int nv = 0, nt = 0, ns = 0;
+    if (!bin_trace(p, T.w0 / 32, T.h_tile, dir_kept, s, inside))
+      bvh_trace<0, true>(p, origin, dir_kept, s, inside, nv, nt, ns);
+    hr.t = s.tmax;
+    hr.v = s.v;
+    hr.idx = (int32_t)s.key; // kNoKey -> -1
+  } else {
+    if (inside) hr = p.hits[(size_t)lr * p.W + w];
+  }
+  const bool has_hit = inside && (hr.idx >= 0);
 
   // ---- main.cpp:723-738 normal of the hit (per-lane gathers, once per pixel)
   f3 N = mk(0.f, 0.f, 0.f);
@@ -2174,8 +2173,7 @@ extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, 
   using esc::v2f;
   const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
   const int shade_grid = ((p->W + 31) / 32) * tiles_y;
-  if (stage == esc::STAGE_BVH) {
-    launch_primary<esc::STAGE_BVH, float, 1>(p, stream);
+  if (stage == esc::STAGE_BVH) { // one kernel: closest hit + shading
     hipLaunchKernelGGL((esc::k_shade<esc::STAGE_BVH>), dim3(shade_grid), dim3(256), 0, stream, *p);
   } else if (stage == esc::STAGE_LDS) {
     if (px == 1) launch_primary<esc::STAGE_LDS, float, 1>(p, stream);
