@@ -56,8 +56,9 @@ def parse():
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
     ap.add_argument("--gather", default="f32", choices=["f32", "u8"],
                     help="what rank 0 collects: fp32 RGB (the seam's return_image) or PPM bytes")
-    ap.add_argument("--cpu-rows", type=int, default=768,
-                    help="rows of the frame the CPU baseline renders (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=-1,
+                    help="rows of the frame the CPU baseline renders (0 = skip, -1 = as many as "
+                         "fit ~15 s of CPU work: 768 on c4, 34 on c5, all on c2/c3)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo lets several ranks share one GPU to rehearse the N>1 path")
     ap.add_argument("--verify-rows", type=int, default=0,
@@ -335,6 +336,9 @@ def main():
                                       "FMA as 2 flop and this kernel may not fuse (bit parity), so "
                                       "0.5 is the ceiling"},
         }
+        if world == 1 and a.cpu_rows < 0:
+            # bounded sample: ~3e9 ray-primitive tests per second on the box's 16 host cores
+            a.cpu_rows = int(max(8, min(H, 15 * 3e9 / (W * max(n_tri + n_sph, 1) * 1.7))))
         if world == 1 and a.cpu_rows > 0:
             gpu_frame = None
             if not use_u8:
