@@ -54,8 +54,10 @@ def parse():
                          "makes the opt-in acceleration structure the measured path")
     ap.add_argument("--no-accel", action="store_true",
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
-    ap.add_argument("--gather", default="f32", choices=["f32", "u8"],
-                    help="what rank 0 collects: fp32 RGB (the seam's return_image) or PPM bytes")
+    ap.add_argument("--gather", default="auto", choices=["auto", "f32", "u8"],
+                    help="what rank 0 collects: fp32 RGB (the seam's return_image) or the PPM-"
+                         "quantised bytes k_shade writes (main.cpp:676-682; 4x fewer bytes over "
+                         "xGMI, SURVEY.md 8(f)2).  auto = fp32 on one GPU, u8 when there is a gather")
     ap.add_argument("--cpu-rows", type=int, default=-1,
                     help="rows of the frame the CPU baseline renders (0 = skip, -1 = as many as "
                          "fit ~15 s of CPU work: 768 on c4, 34 on c5, all on c2/c3)")
@@ -188,7 +190,7 @@ def main():
     S = multigpu.STRIP_ROWS
     my_rows = multigpu.local_rows(H, rank, world, S)
     max_rows = multigpu.max_local_rows(H, world, S)
-    use_u8 = a.gather == "u8"
+    use_u8 = a.gather == "u8" or (a.gather == "auto" and world > 1)
     ch_dtype = torch.uint8 if use_u8 else torch.float32
     n_local = max_rows * W * 3
     # N>1: two strip buffers so the gather of frame i (second stream) overlaps the render of
@@ -350,7 +352,7 @@ def main():
         if world == 1 and a.stage != "bvh" and not a.no_accel and not use_u8:
             out["accel"] = accel_leg(esc, r, st, cam, eye, W, H, shadows, a.steps, a.warmup,
                                      local[0], alg_bytes)
-        if world > 1 and a.verify_rows > 0 and not use_u8:
+        if world > 1 and a.verify_rows > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import numpy as np
 
@@ -359,8 +361,11 @@ def main():
             ref, _ = ol.oracle_render_rows(ol.scene_from_product(scene), eye, look, W, H, rows,
                                            shadows=shadows, threads=host_cores())
             got = frame.view(H, W, 3)[rows].cpu().numpy()
-            out["assembled_frame_rows_bit_exact"] = bool(
-                np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
+            if use_u8:  # the PPM bytes of the same rows (main.cpp:676-682 clamp + truncate)
+                same = np.array_equal(got, ol.oracle_quantise(ref))
+            else:
+                same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+            out["assembled_frame_rows_bit_exact"] = bool(same)
         print(json.dumps(out), flush=True)
 
     if world > 1:

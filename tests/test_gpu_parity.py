@@ -275,7 +275,8 @@ def test_strips_gather_assemble(esc, renderer, world):
             assert np.array_equal(got, ref)
 
 
-def test_bench_two_ranks_gloo_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("gather", ["auto", "f32"])
+def test_bench_two_ranks_gloo_on_one_gpu(tmp_path, gather):
     """bench.py's N>1 path end to end (strips -> gather -> assemble -> reduced counters) with two
     gloo ranks sharing the one GPU; rank 0 checks rows of the assembled frame against the oracle.
     (Real runs use RCCL, one rank per GPU; this rehearses everything but the transport.)"""
@@ -292,13 +293,14 @@ def test_bench_two_ranks_gloo_on_one_gpu(tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ol.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--backend", "gloo", "--config", "c3", "--width", "640", "--height", "360",
-           "--verify-rows", "12"]
+           "--verify-rows", "12", "--gather", gather]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong"
     assert out["assembled_frame_rows_bit_exact"] is True
+    assert ("u8" if gather == "auto" else "fp32") in out["config"]["gather"]
     assert out["config"]["primary_rays_per_frame"] == 640 * 360
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
 
