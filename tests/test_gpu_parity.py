@@ -585,3 +585,40 @@ def test_bvh_light_bins_awkward_lights(esc, renderer, case):
     gpu, u8, ref = render_both(esc, renderer, d, eye, look, 224, 128, stage=esc.ESC_STAGE_BVH)
     assert_bit_equal(gpu, ref, f"bvh light bins/{case}")
     assert ref.sum() > 0
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_bvh_random_scenes(esc, renderer, seed):
+    """random triangle soup + spheres + 1..3 one-face lights, random camera inside or outside:
+    brute force and the BVH stage (tree, screen bins, light bins) both equal the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    n_tri = int(rng.integers(1, 400))
+    n_sph = int(rng.integers(0, 300))
+    c = rng.uniform(-4, 4, (n_tri, 1, 3))
+    tri = (c + rng.normal(0, rng.uniform(0.05, 1.5), (n_tri, 3, 3))).astype(np.float32)
+    geoms = []
+    per = max(1, n_tri // 5)
+    for k in range(0, n_tri, per):  # a few geometries, one material each
+        t = tri[k:k + per].reshape(-1, 3)
+        col = rng.uniform(0.1, 0.9, 3)
+        geoms.append({"vertex": t, "face_index": np.arange(len(t)).reshape(-1, 3),
+                      "material": ol.material13(ka=col, kd=col)})
+    for _ in range(int(rng.integers(1, 4))):
+        p0 = rng.uniform(-5, 5, 3) + np.array([0, 6, 0])
+        lt = np.stack([p0, p0 + rng.normal(0, 0.3, 3), p0 + rng.normal(0, 0.3, 3)])
+        geoms.append({"vertex": lt.astype(np.float32), "face_index": np.array([[0, 1, 2]]),
+                      "material": ol.material13(ka=(.5,) * 3, kd=(.5,) * 3, ke=(9, 8, 7))})
+    sph = np.concatenate([rng.uniform(-4, 4, (n_sph, 3)), rng.uniform(0.03, 0.8, (n_sph, 1))], 1)
+    mats = np.stack([ol.material13(ka=m, kd=m) for m in rng.uniform(0.1, 0.9, (max(n_sph, 1), 3))])
+    d = ol.scene_dict(geoms, sph.astype(np.float32), mats[:n_sph])
+    eye = tuple(float(x) for x in rng.uniform(-6, 6, 3))
+    look = tuple(float(x) for x in rng.uniform(-2, 2, 3))
+    W, H = 168, 104
+    sc = ol.scene_to_product(d)
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    ref = ol.oracle_render(d, eye, look, W, H, threads=8)
+    brute = renderer.render(cam, W, H)
+    assert_bit_equal(brute, ref, f"random/{seed}/brute")
+    bvh = renderer.render(cam, W, H, stage=esc.ESC_STAGE_BVH)
+    assert_bit_equal(bvh, ref, f"random/{seed}/bvh")
