@@ -1,0 +1,729 @@
+// rt_brute.h -- the brute-force primitive loops (main.cpp:176-192 closest hit, :314-329 any hit)
+// over wave-uniform records: software-pipelined fetches, hand-scheduled packed-fp32 sphere bodies,
+// and the re-packing of undecided shadow rays inside a workgroup.  Included by rt_kernels.hip only.
+#pragma once
+#include <float.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+#include "rt_math.h"
+
+namespace esc {
+// ---------------------------------------------------------------------------------------
+// primitive loops.  `rec(k)` yields record k wave-uniformly (SGPRs or LDS broadcast).
+//
+// Every lane carries PX pixels (same row, 16 columns apart).  A wave therefore amortises each
+// primitive fetch, each wave-uniform branch and each s_waitcnt over PX x 64 rays instead of
+// 64: at PX = 1 the rocprofv3 counters showed the VALU pipe 66 % busy with a quarter of all
+// wave-cycles parked on scalar-load waits (profiles/r01_c4_1gpu); the arithmetic per ray is
+// unchanged.
+// ---------------------------------------------------------------------------------------
+
+struct Hit {
+  float t;     // main.cpp:715 FLT_MAX, then closest t
+  float v;     // quirk S1: only v survives (main.cpp:307,310)
+  int32_t idx; // -1 none; [0,n_tri) triangle; n_tri + k sphere k
+};
+
+// Every loop below is software-pipelined by hand: the records of the NEXT batch are fetched
+// (s_load_dwordx8/x16, or ds_read_b128) before the current batch is tested, in two
+// alternating register sets, so a wave never waits on the fetch it just issued.
+
+template <typename Rec, int B, typename Fetch>
+DEVINL void fetch_batch(Fetch rec, int k, Rec (&r)[B]) {
+#pragma unroll
+  for (int i = 0; i < B; ++i) r[i] = rec(k + i);
+  // hipcc's scheduler otherwise sinks the fetch to just above its first use (measured in the
+  // ISA: the s_load landed 4 instructions before the s_waitcnt); pin it where it is written.
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- closest hit, primary rays, triangles ------------------------------------------------
+template <typename V, int NV>
+DEVINL void test_tri2_primary(const DevTriP (&T)[2], int idx, const V3<V> (&d)[NV],
+                              Hit (&h)[NV * lanes_of<V>::n]) {
+  constexpr int LN = lanes_of<V>::n;
+  V det[NV][2], un[NV][2], vn[NV][2];
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const V3<V> pv = cross_vu(d[j], ld3(T[i].e2)); // ray_triangle.h:18
+      det[j][i] = dotu(ld3(T[i].e1), pv);            // :21
+      un[j][i] = dotu(ld3(T[i].tv), pv);             // :32 numerator
+      vn[j][i] = dotu(ld3(T[i].qv), d[j]);           // :40 numerator (dot is commutative per term)
+#pragma unroll
+      for (int c = 0; c < LN; ++c)
+        any |= tri_candidate(comp(det[j][i], c), comp(un[j][i], c), comp(vn[j][i], c));
+    }
+  if (ANY_LANE_RARE(any)) { // wave-uniform skip of the f64 tail
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int c = 0; c < LN; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          Hit &hh = h[j * LN + c];
+          const float de = comp(det[j][i], c), u = comp(un[j][i], c), v = comp(vn[j][i], c);
+          float t2, v2;
+          if (tri_candidate(de, u, v) && tri_exact(de, u, v, T[i].tnum, hh.t, t2, v2)) {
+            hh.t = t2;
+            hh.v = v2;
+            hh.idx = idx + i;
+          }
+        }
+  }
+}
+
+template <typename V, int NV, typename Fetch>
+DEVINL void closest_tri_primary(Fetch rec, int n, int base, const V3<V> (&d)[NV],
+                                Hit (&h)[NV * lanes_of<V>::n]) {
+  const int n4 = n & ~3;
+  if (n4) {
+    DevTriP A[2], B[2];
+    fetch_batch(rec, 0, A);
+    for (int k = 0; k < n4; k += 4) {
+      fetch_batch(rec, rec.landed(A[1].tnum, k + 2), B);
+      test_tri2_primary<V, NV>(A, base + k, d, h);
+      fetch_batch(rec, rec.landed(B[1].tnum, min(k + 4, n - 2)), A); // clamped: last one unused
+      test_tri2_primary<V, NV>(B, base + k + 2, d, h);
+    }
+  }
+  for (int k = n4; k + 1 <= n; k += 1) {
+    // remainder: reuse the pair body with the last record duplicated as a dead second slot
+    DevTriP P[2] = {rec(k), rec(k)};
+    P[1].e1[0] = P[1].e1[1] = P[1].e1[2] = 0.f; // det = 0 -> |det| < eps -> rejected
+    P[1].tv[0] = P[1].tv[1] = P[1].tv[2] = 0.f;
+    P[1].qv[0] = P[1].qv[1] = P[1].qv[2] = 0.f;
+    test_tri2_primary<V, NV>(P, base + k, d, h);
+  }
+}
+
+// ---- hand-scheduled packed-fp32 bodies (2 pixels per lane, SGPR operands) ----------------------
+// hipcc's own v2f code for these tests spends a v_mov per hi-half broadcast and serialises the
+// dependent v_pk chains (s_nop hazards); measured, it is no faster than scalar code.  Written by
+// hand: every sphere constant is read straight from its SGPR pair through op_sel (lo or hi half
+// to both lanes), the independent chains of the batch are interleaved so no v_pk result is
+// consumed by the next instruction, and nothing but v_pk_mul_f32 / v_pk_add_f32 (with neg
+// modifiers, which are exact) is used -- each half rounds exactly like the scalar v_mul / v_add /
+// v_sub of the generic path, in the same order.
+// The "any candidate?" filter works on the raw bits: a value is non-negative iff its bit
+// pattern is >= 0 as a signed int (a disc of -0 cannot occur: b*b is >= +0 and x - x = +0).
+struct SphP2 { // DevSphP seen as two aligned pairs: (ocx, ocy), (ocz, cc)
+  v2f xy, zc;
+};
+struct Sph2 { // DevSph: (cx, cy), (cz, r2)
+  v2f xy, zr;
+};
+
+DEVINL int max3i(int a, int b, int c) { return max(max(a, b), c); }
+DEVINL bool any_nonneg(v2f a, v2f b, v2f c, v2f d) {
+  int m = max3i(__float_as_int(a.x), __float_as_int(a.y), __float_as_int(b.x));
+  m = max3i(m, __float_as_int(b.y), __float_as_int(c.x));
+  m = max3i(m, __float_as_int(c.y), __float_as_int(d.x));
+  m = max(m, __float_as_int(d.y));
+  return m >= 0;
+}
+
+// primary rays, 4 spheres x 2 pixels: b = (ocx*dx + ocy*dy) + ocz*dz ; q = b*b - cc
+DEVINL void sph4_primary_pk(const SphP2 (&s)[4], v2f dx, v2f dy, v2f dz, v2f (&b)[4], v2f (&q)[4]) {
+  asm("v_pk_mul_f32 %0, %[s0a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %1, %[s1a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %2, %[s2a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %3, %[s3a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %4, %[s0a], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %5, %[s1a], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %6, %[s2a], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %7, %[s3a], %[y] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_add_f32 %0, %0, %4\n\t"
+      "v_pk_add_f32 %1, %1, %5\n\t"
+      "v_pk_add_f32 %2, %2, %6\n\t"
+      "v_pk_add_f32 %3, %3, %7\n\t"
+      "v_pk_mul_f32 %4, %[s0b], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %5, %[s1b], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %6, %[s2b], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %7, %[s3b], %[z] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, %4\n\t"
+      "v_pk_add_f32 %1, %1, %5\n\t"
+      "v_pk_add_f32 %2, %2, %6\n\t"
+      "v_pk_add_f32 %3, %3, %7\n\t"
+      "v_pk_mul_f32 %4, %0, %0\n\t"
+      "v_pk_mul_f32 %5, %1, %1\n\t"
+      "v_pk_mul_f32 %6, %2, %2\n\t"
+      "v_pk_mul_f32 %7, %3, %3\n\t"
+      "v_pk_add_f32 %4, %4, %[s0b] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %5, %5, %[s1b] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %6, %6, %[s2b] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %7, %7, %[s3b] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]),
+        "=&v"(q[3])
+      : [x] "v"(dx), [y] "v"(dy), [z] "v"(dz), [s0a] "s"(s[0].xy), [s0b] "s"(s[0].zc),
+        [s1a] "s"(s[1].xy), [s1b] "s"(s[1].zc), [s2a] "s"(s[2].xy), [s2b] "s"(s[2].zc),
+        [s3a] "s"(s[3].xy), [s3b] "s"(s[3].zc));
+}
+
+// shadow rays, 2 spheres x 2 pixels:
+//   oc = o - c ; b = (ocx*Lx + ocy*Ly) + ocz*Lz ; cc = ((ocx*ocx + ocy*ocy) + ocz*ocz) - r2 ;
+//   q = b*b - cc
+DEVINL void sph2_any_pk(const Sph2 (&s)[2], v2f ox, v2f oy, v2f oz, v2f Lx, v2f Ly, v2f Lz,
+                        v2f (&b)[2], v2f (&q)[2]) {
+  v2f ax, ay, az, bx, by, bz, t0, t1; // oc of sphere A / B, temporaries
+  asm("v_pk_add_f32 %[ax], %[ox], %[sAxy] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bx], %[ox], %[sBxy] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay], %[oy], %[sAxy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[by], %[oy], %[sBxy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az], %[oz], %[sAzr] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bz], %[oz], %[sBzr] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      // b = dot(oc, L)
+      "v_pk_mul_f32 %[bA], %[ax], %[Lx]\n\t"
+      "v_pk_mul_f32 %[bB], %[bx], %[Lx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[Ly]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[Ly]\n\t"
+      "v_pk_add_f32 %[bA], %[bA], %[t0]\n\t"
+      "v_pk_add_f32 %[bB], %[bB], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[Lz]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[Lz]\n\t"
+      "v_pk_add_f32 %[bA], %[bA], %[t0]\n\t"
+      "v_pk_add_f32 %[bB], %[bB], %[t1]\n\t"
+      // dot(oc, oc)
+      "v_pk_mul_f32 %[qA], %[ax], %[ax]\n\t"
+      "v_pk_mul_f32 %[qB], %[bx], %[bx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[ay]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[by]\n\t"
+      "v_pk_add_f32 %[qA], %[qA], %[t0]\n\t"
+      "v_pk_add_f32 %[qB], %[qB], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[az]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[bz]\n\t"
+      "v_pk_add_f32 %[qA], %[qA], %[t0]\n\t"
+      "v_pk_add_f32 %[qB], %[qB], %[t1]\n\t"
+      // cc = dot - r2
+      "v_pk_add_f32 %[qA], %[qA], %[sAzr] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[qB], %[qB], %[sBzr] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      // q = b*b - cc
+      "v_pk_mul_f32 %[t0], %[bA], %[bA]\n\t"
+      "v_pk_mul_f32 %[t1], %[bB], %[bB]\n\t"
+      "v_pk_add_f32 %[qA], %[t0], %[qA] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[qB], %[t1], %[qB] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [bA] "=&v"(b[0]), [bB] "=&v"(b[1]), [qA] "=&v"(q[0]), [qB] "=&v"(q[1]), [ax] "=&v"(ax),
+        [ay] "=&v"(ay), [az] "=&v"(az), [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz),
+        [t0] "=&v"(t0), [t1] "=&v"(t1)
+      : [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [Lx] "v"(Lx), [Ly] "v"(Ly), [Lz] "v"(Lz),
+        [sAxy] "s"(s[0].xy), [sAzr] "s"(s[0].zr), [sBxy] "s"(s[1].xy), [sBzr] "s"(s[1].zr));
+}
+
+// ---- 1 pixel per lane, TWO SPHERES per packed op -------------------------------------------
+// Same idea with the roles swapped: the lane keeps one ray and the two halves of every v_pk op
+// hold spheres 2j and 2j+1, whose constants arrive pair-interleaved (DevSphPairP) and feed the
+// ops as plain SGPR pairs; the ray's components are broadcast to both halves through op_sel.
+// Measured on c4: primary pass 11.4 -> 10.4 ms.  The 32-op shadow body gains nothing by itself
+// (13.1 vs 12.6 ms scalar: its v_pk ops run at ~8 cycles instead of ~4, the register pairs hipcc
+// hands to an opaque asm collide in the VGPR banks), but it must be packed too: with a packed
+// primary pass and a SCALAR shadow pass sharing the SIMDs the frame took 30.9 ms (rocprofv3:
+// fewer VALU instructions, +48 % issue stalls), against 23.5 ms packed/packed and 24.0 ms
+// scalar/scalar.
+struct PairP { // DevSphPairP as four aligned pairs
+  v2f x, y, z, c;
+};
+struct PairG { // DevSphPair
+  v2f x, y, z, r;
+};
+
+// primary: b = (ocx*dx + ocy*dy) + ocz*dz ; q = b*b - cc, for records R0 (spheres 0,1), R1 (2,3)
+DEVINL void pair2_primary_pk(const PairP (&R)[2], v2f dxy, v2f dz_, v2f (&b)[2], v2f (&q)[2]) {
+  v2f t0, t1;
+  asm("v_pk_mul_f32 %[b0], %[r0x], %[dxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b1], %[r1x], %[dxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t0], %[r0y], %[dxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t1], %[r1y], %[dxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_mul_f32 %[t0], %[r0z], %[dz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[r1z], %[dz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_mul_f32 %[q0], %[b0], %[b0]\n\t"
+      "v_pk_mul_f32 %[q1], %[b1], %[b1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[r0c] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[r1c] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [q0] "=&v"(q[0]), [q1] "=&v"(q[1]), [t0] "=&v"(t0),
+        [t1] "=&v"(t1)
+      : [dxy] "v"(dxy), [dz] "v"(dz_), [r0x] "s"(R[0].x), [r0y] "s"(R[0].y), [r0z] "s"(R[0].z),
+        [r0c] "s"(R[0].c), [r1x] "s"(R[1].x), [r1y] "s"(R[1].y), [r1z] "s"(R[1].z),
+        [r1c] "s"(R[1].c));
+}
+
+// shadow: oc = o - c ; b = (ocx*Lx + ocy*Ly) + ocz*Lz ; cc = ((ocx^2 + ocy^2) + ocz^2) - r2 ;
+// q = b*b - cc, for records R0 (spheres 0,1) and R1 (spheres 2,3)
+DEVINL void pair2_any_pk(const PairG (&R)[2], v2f oxy, v2f oz_, v2f Lxy, v2f Lz_, v2f (&b)[2],
+                         v2f (&q)[2]) {
+  // Scheduling rule measured in tools/ubench/valu_rate.hip (modes 8/10): a v_pk result must not
+  // be consumed within the next 3 instructions of the same wave (other waves do not fill the
+  // gap): 227 -> 148 cycles per block.  Four chains are kept in flight: dot(oc,L) and dot(oc,oc)
+  // of record 0 and of record 1.
+  v2f ax, ay, az, bx, by, bz, t0, t1, u0, u1;
+  asm("v_pk_add_f32 %[ax], %[oxy], %[r0x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bx], %[oxy], %[r1x] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ay], %[oxy], %[r0y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[by], %[oxy], %[r1y] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[az], %[oz], %[r0z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[bz], %[oz], %[r1z] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[b0], %[ax], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[b1], %[bx], %[Lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[q0], %[ax], %[ax]\n\t"
+      "v_pk_mul_f32 %[q1], %[bx], %[bx]\n\t"
+      "v_pk_mul_f32 %[t0], %[ay], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[t1], %[by], %[Lxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[u0], %[ay], %[ay]\n\t"
+      "v_pk_mul_f32 %[u1], %[by], %[by]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[u0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[u1]\n\t"
+      "v_pk_mul_f32 %[t0], %[az], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[t1], %[bz], %[Lz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[u0], %[az], %[az]\n\t"
+      "v_pk_mul_f32 %[u1], %[bz], %[bz]\n\t"
+      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
+      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[u0]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[u1]\n\t"
+      "v_pk_mul_f32 %[t0], %[b0], %[b0]\n\t"
+      "v_pk_mul_f32 %[t1], %[b1], %[b1]\n\t"
+      "v_pk_add_f32 %[q0], %[q0], %[r0r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[q1], %[r1r] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 1\n\t"
+      "v_pk_add_f32 %[q0], %[t0], %[q0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[q1], %[t1], %[q1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 0"
+      : [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [q0] "=&v"(q[0]), [q1] "=&v"(q[1]), [ax] "=&v"(ax),
+        [ay] "=&v"(ay), [az] "=&v"(az), [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz),
+        [t0] "=&v"(t0), [t1] "=&v"(t1), [u0] "=&v"(u0), [u1] "=&v"(u1)
+      : [oxy] "v"(oxy), [oz] "v"(oz_), [Lxy] "v"(Lxy), [Lz] "v"(Lz_), [r0x] "s"(R[0].x),
+        [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0r] "s"(R[0].r), [r1x] "s"(R[1].x),
+        [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1r] "s"(R[1].r));
+}
+
+// closest hit over pair records [0, n_rec): each record = spheres base+2j, base+2j+1
+template <typename Fetch>
+DEVINL void closest_sph_primary_pairs(Fetch rec, int n_rec, int base, f3 d, Hit &h) {
+  const v2f dxy = {d.x, d.y}, dz_ = {d.z, 0.f};
+  auto test = [&](const PairP(&R)[2], int idx) {
+    v2f b[2], q[2];
+    pair2_primary_pk(R, dxy, dz_, b, q);
+    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                      __float_as_int(q[1].y));
+    if (ANY_LANE_RARE(m >= 0)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { // index order: record i, half c
+          float t2;
+          if (sph_exact(comp(b[i], c), comp(q[i], c), h.t, t2)) {
+            h.t = t2;
+            h.idx = idx + 2 * i + c;
+          }
+        }
+    }
+  };
+  const int n4 = n_rec & ~3;
+  if (n4) {
+    PairP A[2], B[2];
+    fetch_batch(rec, 0, A);
+    for (int k = 0; k < n4; k += 4) {
+      fetch_batch(rec, rec.landed(A[1].c, k + 2), B);
+      test(A, base + 2 * k);
+      fetch_batch(rec, rec.landed(B[1].c, min(k + 4, n_rec - 2)), A);
+      test(B, base + 2 * k + 4);
+    }
+  }
+  for (int k = n4; k < n_rec; ++k) { // < 4 records left: pair each with itself (idempotent)
+    const PairP R[2] = {rec(k), rec(k)};
+    v2f b[2], q[2];
+    pair2_primary_pk(R, dxy, dz_, b, q);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float t2;
+      if (sph_exact(comp(b[0], c), comp(q[0], c), h.t, t2)) {
+        h.t = t2;
+        h.idx = base + 2 * k + c;
+      }
+    }
+  }
+}
+
+// ---- closest hit, primary rays, spheres ---------------------------------------------------
+template <typename V, int NV, int NB>
+DEVINL void test_sph_primary(const DevSphP (&s)[NB], int idx, const V3<V> (&d)[NV],
+                             Hit (&h)[NV * lanes_of<V>::n]) {
+  constexpr int LN = lanes_of<V>::n;
+  V b[NV][NB], q[NV][NB];
+  float m = -1.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      b[j][i] = (s[i].ocx * d[j].x + s[i].ocy * d[j].y) + s[i].ocz * d[j].z;
+      q[j][i] = b[j][i] * b[j][i] - s[i].cc;
+#pragma unroll
+      for (int c = 0; c < LN; ++c) m = fmaxf(m, comp(q[j][i], c));
+    }
+  if (ANY_LANE_RARE(!(m < 0.f))) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int c = 0; c < LN; ++c)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          Hit &hh = h[j * LN + c];
+          float t2;
+          if (sph_exact(comp(b[j][i], c), comp(q[j][i], c), hh.t, t2)) {
+            hh.t = t2;
+            hh.idx = idx + i;
+          }
+        }
+  }
+}
+
+template <typename V, int NV, typename Fetch>
+DEVINL void closest_sph_primary(Fetch rec, int n, int base, const V3<V> (&d)[NV],
+                                Hit (&h)[NV * lanes_of<V>::n]) {
+  const int n8 = n & ~7;
+  if (n8) {
+    DevSphP A[4], B[4];
+    fetch_batch(rec, 0, A);
+    for (int k = 0; k < n8; k += 8) {
+      fetch_batch(rec, rec.landed(A[3].cc, k + 4), B);
+      test_sph_primary<V, NV, 4>(A, base + k, d, h);
+      fetch_batch(rec, rec.landed(B[3].cc, min(k + 8, n - 4)), A);
+      test_sph_primary<V, NV, 4>(B, base + k + 4, d, h);
+    }
+  }
+  for (int k = n8; k < n; ++k) {
+    const DevSphP s0[1] = {rec(k)};
+    test_sph_primary<V, NV, 1>(s0, base + k, d, h);
+  }
+}
+
+// SMEM + 2 pixels per lane: the hand-scheduled packed body above
+template <typename Fetch>
+DEVINL void closest_sph_primary_pk(Fetch rec, int n, int base, const V3<v2f> &d, Hit (&h)[2]) {
+  auto test4 = [&](const SphP2(&S)[4], int idx) {
+    v2f b[4], q[4];
+    sph4_primary_pk(S, d.x, d.y, d.z, b, q);
+    if (ANY_LANE_RARE(any_nonneg(q[0], q[1], q[2], q[3]))) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t2;
+          if (sph_exact(comp(b[i], c), comp(q[i], c), h[c].t, t2)) {
+            h[c].t = t2;
+            h[c].idx = idx + i;
+          }
+        }
+    }
+  };
+  const int n8 = n & ~7;
+  if (n8) {
+    SphP2 A[4], B[4];
+    fetch_batch(rec, 0, A);
+    for (int k = 0; k < n8; k += 8) {
+      fetch_batch(rec, rec.landed(A[3].zc, k + 4), B);
+      test4(A, base + k);
+      fetch_batch(rec, rec.landed(B[3].zc, min(k + 8, n - 4)), A);
+      test4(B, base + k + 4);
+    }
+  }
+}
+
+// ---- any-hit (main.cpp:314-329), general origin -------------------------------------------
+// Per-pixel state of one occlusion() call.  tb is the bound: > 0 while the ray is still
+// looking, set to 0 once it found its FIRST occluder (or if it never looked), so later
+// primitives cannot accept (accepts need eps <= t2 < tb).  tocc receives that occluder's t2
+// (occlusion() mutates the caller's t, quirk S3) and kocc its index in (triangles, spheres)
+// order.  The wave leaves a loop early once no ray is looking (checked per block of
+// kExitStride primitives, not per primitive).
+struct Any {
+  float tb;
+  float tocc;
+  int32_t kocc;
+};
+// Each check drains the fetch pipeline (the next block's s_load is re-issued cold), so it is
+// taken every 256 primitives, not more often: overshooting an exit by < 256 of 10^4..10^5
+// primitives costs far less than a cold scalar load per 32.
+constexpr int kExitStride = 32;
+
+template <int PX> DEVINL bool any_looking(const Any (&a)[PX]) {
+  bool l = false;
+#pragma unroll
+  for (int p = 0; p < PX; ++p) l |= a[p].tb > 0.f;
+  return __builtin_amdgcn_ballot_w64(l) != 0;
+}
+
+template <typename V, int NV>
+DEVINL void test_tri_any(const DevTri &T, int idx, const V3<V> (&o)[NV], const V3<V> (&L)[NV],
+                         Any (&a)[NV * lanes_of<V>::n]) {
+  constexpr int LN = lanes_of<V>::n;
+  const f3 e1 = ld3(T.e1), e2 = ld3(T.e2), v0 = ld3(T.v0);
+  V det[NV], un[NV], vn[NV];
+  V3<V> qv[NV];
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const V3<V> pv = cross_vu(L[j], e2); // ray_triangle.h:18
+    det[j] = dotu(e1, pv);               // :21
+    const V3<V> tv = sub_u(o[j], v0);    // :29
+    un[j] = dotv(tv, pv);                // :32
+    qv[j] = cross_vu(tv, e1);            // :37
+    vn[j] = dotv(L[j], qv[j]);           // :40
+#pragma unroll
+    for (int c = 0; c < LN; ++c)
+      any |= tri_candidate(comp(det[j], c), comp(un[j], c), comp(vn[j], c));
+  }
+  if (ANY_LANE_RARE(any)) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const V tn = dotu(e2, qv[j]); // :45 numerator
+#pragma unroll
+      for (int c = 0; c < LN; ++c) {
+        Any &aa = a[j * LN + c];
+        const float de = comp(det[j], c), u = comp(un[j], c), v = comp(vn[j], c);
+        float t2, v2;
+        if (tri_candidate(de, u, v) && tri_exact(de, u, v, comp(tn, c), aa.tb, t2, v2)) {
+          aa.tocc = t2;
+          aa.kocc = idx;
+          aa.tb = 0.f;
+        }
+      }
+    }
+  }
+}
+
+template <typename V, int NV, typename Fetch>
+DEVINL void anyhit_tri(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V3<V> (&L)[NV],
+                       Any (&a)[NV * lanes_of<V>::n]) {
+  for (int k0 = 0; k0 < n; k0 += kExitStride) {
+    if (!any_looking(a)) return; // every ray done
+    const int m = min(kExitStride, n - k0);
+    const int m2 = m & ~1;
+    if (m2) {
+      DevTri A = rec(k0), B;
+      for (int k = 0; k < m2; k += 2) {
+        B = rec(rec.landed(A.e2[2], k0 + k + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        test_tri_any<V, NV>(A, base + k0 + k, o, L, a);
+        A = rec(rec.landed(B.e2[2], k0 + min(k + 2, m - 1)));
+        __builtin_amdgcn_sched_barrier(0);
+        test_tri_any<V, NV>(B, base + k0 + k + 1, o, L, a);
+      }
+    }
+    if (m2 < m) test_tri_any<V, NV>(rec(k0 + m2), base + k0 + m2, o, L, a);
+  }
+}
+
+template <typename V, int NV, int NB>
+DEVINL void test_sph_any(const DevSph (&s)[NB], int idx, const V3<V> (&o)[NV],
+                         const V3<V> (&L)[NV], Any (&a)[NV * lanes_of<V>::n]) {
+  constexpr int LN = lanes_of<V>::n;
+  V b[NV][NB], q[NV][NB];
+  float m = -1.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const V3<V> oc = sub_u(o[j], mk(s[i].cx, s[i].cy, s[i].cz));
+      b[j][i] = dotv(oc, L[j]);
+      q[j][i] = b[j][i] * b[j][i] - (dotv(oc, oc) - s[i].r2);
+#pragma unroll
+      for (int c = 0; c < LN; ++c) m = fmaxf(m, comp(q[j][i], c));
+    }
+  if (ANY_LANE_RARE(!(m < 0.f))) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int c = 0; c < LN; ++c)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          Any &aa = a[j * LN + c];
+          float t2;
+          if (sph_exact(comp(b[j][i], c), comp(q[j][i], c), aa.tb, t2)) {
+            aa.tocc = t2;
+            aa.kocc = idx + i;
+            aa.tb = 0.f;
+          }
+        }
+  }
+}
+
+template <typename V, int NV, typename Fetch>
+DEVINL void anyhit_sph(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V3<V> (&L)[NV],
+                       Any (&a)[NV * lanes_of<V>::n]) {
+  // 4 spheres per fetch (one s_load_dwordx16): scalar loads return out of order, so only ONE
+  // fetch can be in flight behind the one being consumed; a longer block hides more latency
+  constexpr int NB = (NV * lanes_of<V>::n == 1) ? 4 : 2;
+  for (int k0 = 0; k0 < n; k0 += kExitStride) {
+    if (!any_looking(a)) return;
+    const int m = min(kExitStride, n - k0);
+    const int mb = m - m % (2 * NB);
+    if (mb) {
+      DevSph A[NB], B[NB];
+      fetch_batch(rec, k0, A);
+      for (int k = 0; k < mb; k += 2 * NB) {
+        fetch_batch(rec, rec.landed(A[NB - 1].r2, k0 + k + NB), B);
+        test_sph_any<V, NV, NB>(A, base + k0 + k, o, L, a);
+        fetch_batch(rec, rec.landed(B[NB - 1].r2, k0 + min(k + 2 * NB, m - NB)), A);
+        test_sph_any<V, NV, NB>(B, base + k0 + k + NB, o, L, a);
+      }
+    }
+    for (int k = mb; k < m; ++k) {
+      const DevSph s0[1] = {rec(k0 + k)};
+      test_sph_any<V, NV, 1>(s0, base + k0 + k, o, L, a);
+    }
+  }
+}
+
+// SMEM + 2 pixels per lane: hand-scheduled packed body, 2 spheres per batch
+template <typename Fetch>
+DEVINL void anyhit_sph_pk(Fetch rec, int n, int base, const V3<v2f> &o, const V3<v2f> &L,
+                          Any (&a)[2]) {
+  auto test2 = [&](const Sph2(&S)[2], int idx) {
+    v2f b[2], q[2];
+    sph2_any_pk(S, o.x, o.y, o.z, L.x, L.y, L.z, b, q);
+    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                      __float_as_int(q[1].y));
+    if (ANY_LANE_RARE(m >= 0)) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float t2;
+          if (sph_exact(comp(b[i], c), comp(q[i], c), a[c].tb, t2)) {
+            a[c].tocc = t2;
+            a[c].kocc = idx + i;
+            a[c].tb = 0.f;
+          }
+        }
+    }
+  };
+  // n is a multiple of 4 here (the caller peels the remainder)
+  for (int k0 = 0; k0 < n; k0 += kExitStride) {
+    if (!any_looking(a)) return;
+    const int m = min(kExitStride, n - k0);
+    Sph2 A[2], B[2];
+    fetch_batch(rec, k0, A);
+    for (int k = 0; k < m; k += 4) {
+      fetch_batch(rec, rec.landed(A[1].zr, k0 + k + 2), B);
+      test2(A, base + k0 + k);
+      fetch_batch(rec, rec.landed(B[1].zr, k0 + min(k + 4, m - 2)), A);
+      test2(B, base + k0 + k + 2);
+    }
+  }
+}
+
+// any-hit over pair records (1 pixel per lane, two spheres per packed op)
+constexpr int kPairExitRecords = 128; // exit check every 256 spheres (it drains the fetch pipeline)
+template <typename Fetch>
+DEVINL int anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a) {
+  int swept = 0; // pair records this wave actually tested (wave-uniform)
+  const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
+  auto accept = [&](const v2f(&b)[2], const v2f(&q)[2], int idx, int nrec) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= nrec) break;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float t2;
+        if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2)) {
+          a.tocc = t2;
+          a.kocc = idx + 2 * i + c;
+          a.tb = 0.f;
+        }
+      }
+    }
+  };
+  // 8 spheres (4 records) per iteration: two packed bodies, ONE candidate filter, one branch.
+  // No hand prefetch here: other waves cover the scalar-load latency, and a single register
+  // set leaves room for the 32 SGPRs the four records need.
+  auto test4 = [&](const PairG(&R0)[2], const PairG(&R1)[2], int idx) {
+    v2f b0[2], q0[2], b1[2], q1[2];
+    pair2_any_pk(R0, oxy, oz_, Lxy, Lz_, b0, q0);
+    pair2_any_pk(R1, oxy, oz_, Lxy, Lz_, b1, q1);
+    int m = max(max3i(__float_as_int(q0[0].x), __float_as_int(q0[0].y), __float_as_int(q0[1].x)),
+                __float_as_int(q0[1].y));
+    m = max3i(m, __float_as_int(q1[0].x), __float_as_int(q1[0].y));
+    m = max3i(m, __float_as_int(q1[1].x), __float_as_int(q1[1].y));
+    if (ANY_LANE_RARE(m >= 0)) {
+      accept(b0, q0, idx, 2);
+      accept(b1, q1, idx + 4, 2);
+    }
+  };
+  for (int k0 = 0; k0 < n_rec; k0 += kPairExitRecords) {
+    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return swept;
+    const int m = min(kPairExitRecords, n_rec - k0);
+    swept += m;
+    const int m4 = m & ~3;
+    for (int k = 0; k < m4; k += 4) {
+      const PairG R0[2] = {rec(k0 + k), rec(k0 + k + 1)};
+      const PairG R1[2] = {rec(k0 + k + 2), rec(k0 + k + 3)};
+      test4(R0, R1, base + 2 * (k0 + k));
+    }
+    for (int k = m4; k < m; ++k) {
+      const PairG R[2] = {rec(k0 + k), rec(k0 + k)};
+      v2f b[2], q[2];
+      pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+      accept(b, q, base + 2 * (k0 + k), 1);
+    }
+  }
+  return swept;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// re-packing of undecided shadow rays inside a workgroup
+//
+// A wave runs an any-hit loop until its LAST ray is decided, so rays that found their occluder
+// early keep occupying lanes: on c4 only 66 % of the executed lane-tests belong to rays the
+// reference would still be testing.  The primitive list is therefore cut into segments; between
+// segments the workgroup's 256 rays are re-packed through LDS so that the still-undecided ones
+// fill whole waves (wave w takes rays [64w, 64w+64) of the packed list) and the other waves sit
+// the segment out.  Every ray still meets the primitives in index order and stops at its first
+// accepted one, so kocc / tocc -- and the image -- are unchanged.
+// ---------------------------------------------------------------------------------------
+struct RepackLds {
+  float ox[256], oy[256], oz[256]; // shadow-ray origin (main.cpp:757 `hit`)
+  float lx[256], ly[256], lz[256]; // unit direction
+  float tb[256];                   // bound; 0 = decided or never looking
+  float tocc[256];
+  int32_t kocc[256];
+  uint16_t list[256]; // packed position -> owning thread
+  int32_t wave_cnt[4];
+};
+constexpr int kSegTris = 256;     // primitives per segment between re-packs
+constexpr int kSegSphPairs = 512; // = 1024 spheres
+
+// all 256 threads; returns the number of rays still looking (workgroup-uniform)
+DEVINL int repack_rays(RepackLds &R, int tid) {
+  __syncthreads(); // tb / kocc writes of the previous segment
+  const bool looking = R.tb[tid] > 0.f;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(looking);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (lane == 0) R.wave_cnt[wave] = __popcll(m);
+  __syncthreads();
+  int off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int c = R.wave_cnt[w];
+    off += (w < wave) ? c : 0;
+    total += c;
+  }
+  if (looking) R.list[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(total);
+}
+
+} // namespace esc
