@@ -26,7 +26,7 @@
 //    those -- the BVH mode may in principle cull a hit that brute force reports.  The parity tests
 //    compare whole frames of both modes (tests/test_gpu_parity.py), DESIGN.md states the caveat.
 //
-// The slab test itself (rt_kernels.hip slab()) is off by < 4 u M in position, far inside either
+// The slab test itself (rt_accel.h slab()) is off by < 4 u M in position, far inside either
 // pad.  All pads are computed in double and rounded outward.
 #include "accel_build.h"
 

@@ -5,7 +5,7 @@
 2. conservativeness: for camera rays and shadow rays of small scenes, every primitive the ORACLE's
    exact test accepts (orc_intersect_triangle / orc_intersect_sphere, i.e. the reference
    arithmetic) is reached by a single-ray walk of the tree that uses the kernel's box test
-   (rt_kernels.hip slab(): t = plane * (1/d) - o * (1/d), segment [0, t2 of that accept]).
+   (rt_accel.h slab(): t = plane * (1/d) - o * (1/d), segment [0, t2 of that accept]).
 """
 import ctypes as C
 
@@ -103,7 +103,7 @@ def test_depth_stays_inside_the_stack_for_a_lopsided_scene():
 
 # ---------------------------------------------------------------------------------------------
 def _slab(lo, hi, inv, noinv, tmax):
-    """rt_kernels.hip slab() in fp32 (the fused multiply-add is one rounding of the exact
+    """rt_accel.h slab() in fp32 (the fused multiply-add is one rounding of the exact
     product-sum; float64 holds the product of two floats exactly)."""
     t0 = (lo.astype(np.float64) * inv + noinv).astype(np.float32)
     t1 = (hi.astype(np.float64) * inv + noinv).astype(np.float32)
