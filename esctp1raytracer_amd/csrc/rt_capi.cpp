@@ -393,10 +393,11 @@ int build_accel_device(esc_context *ctx, const float origin[3]) {
     const size_t n_prims = ctx->h_tri.size() + ctx->h_sph.size();
     esc::LightBins &g = ctx->lbins;
     g.n_points = 0;
-    // measured: with ~100k triangles a cell holds more candidates than a tree walk visits
-    // (c5: 15.8 vs 6.5 tests per shadow ray, frame 1.34 vs 1.29 ms), so big scenes keep the walk
-    if (n_pts >= 1 && n_pts <= esc::kLightGridsMax && n_prims > 0 && n_prims <= 32768) {
-      g.R = 64; // measured on c3 / c4: 32..96 within 5 %, finer splits a wave's rays over more cells
+    if (n_pts >= 1 && n_pts <= esc::kLightGridsMax && n_prims > 0) {
+      // cells per cube-face edge, measured (frame ms at R = 64 / 128 / 256): c3 0.217 / 0.213 /
+      // 0.215, c4 0.265 / 0.260 / 0.257, c5 1.21 / 1.13 / 1.00 -- finer pays once a cell would
+      // otherwise overflow; 26 MB per light point at 128, 104 MB at 256
+      g.R = n_prims <= 32768 ? 128 : 256;
       const size_t n_cells = (size_t)n_pts * 6 * g.R * g.R;
       if ((rc = alloc_dev(g.face_hdr, (size_t)n_pts * 6 * esc::kBinHdrInts))) return rc;
       if ((rc = alloc_dev(g.counts, 2 * n_cells))) return rc;

@@ -154,7 +154,7 @@ struct PrimBoxDev {
 // seen from L in the direction of the shaded point.  Directions from L are binned on a cube map
 // (6 faces x R x R cells); k_bin_light projects every padded primitive box onto it once per scene
 // (lights do not move with the camera).  A shadow ray looks up the cell of (hit point - L) and
-// tests that cell's primitives with the exact test.  Per face, primitives that straddle the
+// tests that cell's primitives (per-lane lists) with the exact test.  Per face, primitives that straddle the
 // face's plane through L go to a short face-global list; overflowing cells / lists make the rays
 // that land there walk the tree instead.
 constexpr int kLightGridsMax = 4; // light sample points that get a cube map (more: tree walk only)
