@@ -97,10 +97,13 @@ def accel_leg(esc, r, st, cam, eye, W, H, shadows, steps, warmup, brute_frame, a
     buf = torch.zeros(H * W * 3, dtype=torch.float32, device=brute_frame.device)
     ev = []
     r.synchronize()
+    t0 = 0.0
     for i in range(warmup + steps):
         if i == warmup:
             r.synchronize()
             r.reset_counters()
+            r.synchronize()
+            t0 = time.perf_counter()
         with torch.cuda.stream(st):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -110,12 +113,14 @@ def accel_leg(esc, r, st, cam, eye, W, H, shadows, steps, warmup, brute_frame, a
         if i >= warmup:
             ev.append((e0, e1))
     st.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / steps
     cnt = r.counters()
     ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     rays = (cnt["primary_rays"] + cnt["shadow_rays"]) / steps
     differing = int((buf.view(torch.int32) != brute_frame[:H * W * 3].view(torch.int32)).sum().item())
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return {"stage": "bvh", "value": rays / (ms * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms,
+            "ms_per_step_wall": wall_ms,  # host clock over the same K frames, launches included
             "steps": steps, "timing": "HIP events around the whole frame: memset + k_bin_primary + k_shade<BVH> (closest hit and shading in one kernel)",
             "fp32_values_differing_from_brute_force": differing,
             "identical_to_brute_force": differing == 0,

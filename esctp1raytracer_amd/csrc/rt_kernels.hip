@@ -242,11 +242,10 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     }
 }
 
-#ifndef ESC_SHADE_WAVES
-#define ESC_SHADE_WAVES 6
-#endif
+// waves per SIMD asked of the register allocator: 6 (80 VGPRs) measured best for the SMEM and BVH
+// variants (5 and 4 were 1 % slower / no different); the LDS variant's 46 KB of LDS allow 4
 template <int STAGE>
-__global__ void __launch_bounds__(256, ESC_SHADE_WAVES) k_shade(const RenderParams p) {
+__global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const RenderParams p) {
   typedef float V;
   constexpr int NV = 1;
   constexpr int TW = 32;
