@@ -34,7 +34,9 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 namespace esc {
 
@@ -147,8 +149,8 @@ struct Builder {
   const uint32_t key_base;
   const int max_depth;
   BuiltBvh &out;
-  std::vector<int32_t> idx;
-  std::vector<float> cen; // 3 per primitive
+  std::vector<int32_t> &idx;     // shared permutation; a builder only touches its own range
+  const std::vector<float> &cen; // 3 per primitive
 
   // internal levels a count-balanced (median) subtree over n primitives needs
   int levels_needed(size_t n) const {
@@ -215,44 +217,53 @@ struct Builder {
     if (depth_used + levels_needed(n) >= max_depth || !(chi[wide] > clo[wide])) return median();
 
     constexpr int NB = 16;
-    double best = DBL_MAX;
-    int best_axis = -1, best_bin = -1;
-    for (int a = 0; a < 3; a++) {
-      if (!(chi[a] > clo[a])) continue;
-      struct Bin {
-        float lo[3], hi[3];
-        size_t n;
-      } bins[NB];
-      for (auto &bn : bins) {
+    struct Bin {
+      float lo[3], hi[3];
+      size_t n;
+    };
+    Bin bins[3][NB]; // all three axes binned in ONE pass over the primitives
+    for (auto &ax : bins)
+      for (auto &bn : ax) {
         bn.n = 0;
         for (int k = 0; k < 3; k++) {
           bn.lo[k] = FLT_MAX;
           bn.hi[k] = -FLT_MAX;
         }
       }
-      const double scale = NB / ((double)chi[a] - clo[a]);
-      for (size_t i = b; i < e; i++) {
-        const int32_t k = idx[i];
-        int bi = (int)(((double)cen[3 * (size_t)k + a] - clo[a]) * scale);
+    double scale3[3];
+    for (int a = 0; a < 3; a++)
+      scale3[a] = (chi[a] > clo[a]) ? NB / ((double)chi[a] - clo[a]) : 0.0;
+    for (size_t i = b; i < e; i++) {
+      const int32_t k = idx[i];
+      const PrimBox &pb = boxes[(size_t)k];
+      for (int a = 0; a < 3; a++) {
+        int bi = (int)(((double)cen[3 * (size_t)k + a] - clo[a]) * scale3[a]);
         bi = std::min(std::max(bi, 0), NB - 1);
-        bins[bi].n++;
+        Bin &bn = bins[a][bi];
+        bn.n++;
         for (int q = 0; q < 3; q++) {
-          bins[bi].lo[q] = std::min(bins[bi].lo[q], boxes[k].lo[q]);
-          bins[bi].hi[q] = std::max(bins[bi].hi[q], boxes[k].hi[q]);
+          bn.lo[q] = std::min(bn.lo[q], pb.lo[q]);
+          bn.hi[q] = std::max(bn.hi[q], pb.hi[q]);
         }
       }
+    }
+    double best = DBL_MAX;
+    int best_axis = -1, best_bin = -1;
+    for (int a = 0; a < 3; a++) {
+      if (!(chi[a] > clo[a])) continue;
+      const Bin *bn = bins[a];
       double right_area[NB];
       size_t right_n[NB];
       {
         float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
         size_t cnt = 0;
         for (int j = NB - 1; j >= 1; j--) {
-          if (bins[j].n) {
+          if (bn[j].n) {
             for (int q = 0; q < 3; q++) {
-              lo[q] = std::min(lo[q], bins[j].lo[q]);
-              hi[q] = std::max(hi[q], bins[j].hi[q]);
+              lo[q] = std::min(lo[q], bn[j].lo[q]);
+              hi[q] = std::max(hi[q], bn[j].hi[q]);
             }
-            cnt += bins[j].n;
+            cnt += bn[j].n;
           }
           right_area[j] = cnt ? area(lo, hi) : 0.0;
           right_n[j] = cnt;
@@ -261,12 +272,12 @@ struct Builder {
       float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
       size_t cnt = 0;
       for (int j = 0; j + 1 < NB; j++) { // split between bin j and j+1
-        if (bins[j].n) {
+        if (bn[j].n) {
           for (int q = 0; q < 3; q++) {
-            lo[q] = std::min(lo[q], bins[j].lo[q]);
-            hi[q] = std::max(hi[q], bins[j].hi[q]);
+            lo[q] = std::min(lo[q], bn[j].lo[q]);
+            hi[q] = std::max(hi[q], bn[j].hi[q]);
           }
-          cnt += bins[j].n;
+          cnt += bn[j].n;
         }
         const size_t nr = right_n[j + 1];
         if (cnt == 0 || nr == 0) continue;
@@ -323,6 +334,22 @@ struct Builder {
 
 } // namespace
 
+namespace {
+
+// top of a parallel build: the first few splits are made serially, every range below them is
+// a task some thread builds into its own BuiltBvh; the pieces are then renumbered into one tree
+struct TopNode {
+  int child[2]; // >= 0: TopNode index; < 0: ~task
+};
+struct Task {
+  size_t b, e;
+  int depth;
+  BuiltBvh sub;
+  Sub result;
+};
+
+} // namespace
+
 void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, int max_depth,
                BuiltBvh &out) {
   out.nodes.clear();
@@ -331,14 +358,116 @@ void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, 
   out.depth = 0;
   out.n_blocks = 0;
   if (boxes.empty()) return;
-  Builder B{boxes, block, key_base, max_depth, out, {}, {}};
-  B.idx.resize(boxes.size());
-  std::iota(B.idx.begin(), B.idx.end(), 0);
-  B.cen.resize(3 * boxes.size());
+  std::vector<int32_t> idx(boxes.size());
+  std::iota(idx.begin(), idx.end(), 0);
+  std::vector<float> cen(3 * boxes.size());
   for (size_t i = 0; i < boxes.size(); i++)
-    for (int a = 0; a < 3; a++) B.cen[3 * i + a] = 0.5f * boxes[i].lo[a] + 0.5f * boxes[i].hi[a];
-  out.nodes.reserve(2 * boxes.size() / (size_t)block + 2);
-  const Sub r = B.build(0, boxes.size(), 0);
+    for (int a = 0; a < 3; a++) cen[3 * i + a] = 0.5f * boxes[i].lo[a] + 0.5f * boxes[i].hi[a];
+
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (boxes.size() < 16384 || hw < 2) { // small sets: one thread, pre-order numbering
+    Builder B{boxes, block, key_base, max_depth, out, idx, cen};
+    out.nodes.reserve(2 * boxes.size() / (size_t)block + 2);
+    const Sub r = B.build(0, boxes.size(), 0);
+    out.root = r.code;
+    out.depth = r.depth;
+    return;
+  }
+
+  // ---- serial top: split until the ranges are small enough to hand out
+  std::vector<TopNode> top;
+  std::vector<Task> tasks;
+  const size_t grain = std::max<size_t>(boxes.size() / (2 * hw), 4096);
+  BuiltBvh scratch; // the top splits only permute idx; they emit nothing
+  Builder T{boxes, block, key_base, max_depth, scratch, idx, cen};
+  struct Local {
+    static int make(Builder &T, std::vector<TopNode> &top, std::vector<Task> &tasks, size_t b,
+                    size_t e, int depth, size_t grain) {
+      if (e - b <= grain || depth >= 8) {
+        tasks.push_back(Task{b, e, depth, {}, {}});
+        return ~(int)(tasks.size() - 1);
+      }
+      const int me = (int)top.size();
+      top.push_back(TopNode{{0, 0}});
+      const size_t m = T.split(b, e, depth);
+      const int l = make(T, top, tasks, b, m, depth + 1, grain);
+      const int r = make(T, top, tasks, m, e, depth + 1, grain);
+      top[(size_t)me].child[0] = l;
+      top[(size_t)me].child[1] = r;
+      return me;
+    }
+  };
+  const int top_root = Local::make(T, top, tasks, 0, boxes.size(), 0, grain);
+
+  // ---- the tasks, in parallel (disjoint ranges of idx, private outputs)
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= tasks.size()) return;
+      Task &t = tasks[k];
+      Builder B{boxes, block, key_base, max_depth, t.sub, idx, cen};
+      t.result = B.build(t.b, t.e, t.depth);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned i = 1; i < hw; i++) pool.emplace_back(worker);
+  worker();
+  for (auto &th : pool) th.join();
+
+  // ---- stitch: top nodes first (creation order), then each task's nodes and blocks in task order
+  std::vector<int32_t> node_off(tasks.size()), block_off(tasks.size());
+  int32_t n_nodes = (int32_t)top.size(), n_blocks = 0;
+  for (size_t k = 0; k < tasks.size(); k++) {
+    node_off[k] = n_nodes;
+    block_off[k] = n_blocks;
+    n_nodes += (int32_t)tasks[k].sub.nodes.size();
+    n_blocks += tasks[k].sub.n_blocks;
+  }
+  out.nodes.resize((size_t)n_nodes);
+  out.order.reserve((size_t)n_blocks * (size_t)block);
+  out.n_blocks = n_blocks;
+  auto fix = [&](int32_t code, size_t k) {
+    return code >= 0 ? code + node_off[k] : ~((~code) + block_off[k]);
+  };
+  for (size_t k = 0; k < tasks.size(); k++) {
+    const BuiltBvh &sb = tasks[k].sub;
+    for (size_t i = 0; i < sb.nodes.size(); i++) {
+      BvhNode n = sb.nodes[i];
+      n.child[0] = fix(n.child[0], k);
+      n.child[1] = fix(n.child[1], k);
+      out.nodes[(size_t)node_off[k] + i] = n;
+    }
+    out.order.insert(out.order.end(), sb.order.begin(), sb.order.end());
+    tasks[k].result.code = fix(tasks[k].result.code, k);
+  }
+  struct Stitch {
+    static Sub go(const std::vector<TopNode> &top, const std::vector<Task> &tasks, BuiltBvh &out,
+                  int code) {
+      if (code < 0) return tasks[(size_t)~code].result;
+      const Sub L = go(top, tasks, out, top[(size_t)code].child[0]);
+      const Sub R = go(top, tasks, out, top[(size_t)code].child[1]);
+      BvhNode &N = out.nodes[(size_t)code];
+      std::memcpy(N.lo0, L.lo, 12);
+      std::memcpy(N.hi0, L.hi, 12);
+      std::memcpy(N.lo1, R.lo, 12);
+      std::memcpy(N.hi1, R.hi, 12);
+      N.child[0] = L.code;
+      N.child[1] = R.code;
+      N.minkey[0] = L.minkey;
+      N.minkey[1] = R.minkey;
+      Sub s;
+      s.code = code;
+      s.depth = 1 + std::max(L.depth, R.depth);
+      s.minkey = std::min(L.minkey, R.minkey);
+      for (int a = 0; a < 3; a++) {
+        s.lo[a] = std::min(L.lo[a], R.lo[a]);
+        s.hi[a] = std::max(L.hi[a], R.hi[a]);
+      }
+      return s;
+    }
+  };
+  const Sub r = Stitch::go(top, tasks, out, top_root);
   out.root = r.code;
   out.depth = r.depth;
 }

@@ -59,7 +59,8 @@ def _check_structure(a, n_prims, key_base):
     assert d == a["depth"]
 
 
-@pytest.mark.parametrize("cfg,n", [("c2", 0), ("c3", 333), ("c4", 2049), ("c5", 9), ("c5", 40)])
+@pytest.mark.parametrize("cfg,n", [("c2", 0), ("c3", 333), ("c4", 2049), ("c5", 9), ("c5", 40),
+                                   ("c5", 100)])  # 20,000 triangles: the threaded build
 def test_tree_structure(cfg, n):
     sc = esc.Scene.synthetic(cfg, n)
     info = sc.info()

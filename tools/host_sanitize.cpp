@@ -73,7 +73,7 @@ int main(int argc, char **argv) {
       z = z * 6364136223846793005ull + 1442695040888963407ull;
       return (float)((z >> 40) & 0xFFFF) / 65535.0f;
     };
-    for (int n : {0, 1, 2, 3, 5, 64, 1000}) {
+    for (int n : {0, 1, 2, 3, 5, 64, 1000, 20000}) { // 20000: the threaded build
       std::vector<esc::PrimBox> scattered((size_t)n), same((size_t)n), line((size_t)n);
       float x = 1e-3f;
       for (int i = 0; i < n; i++) {
