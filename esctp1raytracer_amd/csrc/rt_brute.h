@@ -702,6 +702,10 @@ struct RepackLds {
   int32_t kocc[256];
   uint16_t list[256]; // packed position -> owning thread
   int32_t wave_cnt[4];
+  // per-pixel shading state parked here while the any-hit segments run, so it does not hold
+  // VGPRs across them (with it in registers hipcc spilled 6 VGPRs to scratch: +133 MB of HBM
+  // writes per 4K frame)
+  float keep[8][256]; // N.xyz, r, g, b, t, material index
 };
 constexpr int kSegTris = 256;     // primitives per segment between re-packs
 constexpr int kSegSphPairs = 512; // = 1024 spheres

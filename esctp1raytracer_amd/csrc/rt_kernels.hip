@@ -385,6 +385,9 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         R.tb[tid] = a[0].tb;
         R.kocc[tid] = -1;
         R.tocc[tid] = 0.f;
+        R.keep[0][tid] = N.x; R.keep[1][tid] = N.y; R.keep[2][tid] = N.z;
+        R.keep[3][tid] = r; R.keep[4][tid] = g; R.keep[5][tid] = b;
+        R.keep[6][tid] = t; R.keep[7][tid] = __int_as_float(mi);
         // Occluded rays mostly meet their occluder early in the list, so re-packing pays at
         // the beginning and not later: segment lengths double (256, 256, 512, 1024, ...
         // triangles; 512, 512, 1024, ... pair records), which keeps the barriers few.
@@ -435,6 +438,10 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         a[0].kocc = R.kocc[tid];
         a[0].tocc = R.tocc[tid];
         rL = mk(R.lx[tid], R.ly[tid], R.lz[tid]); // not kept live across the segments
+        N = mk(R.keep[0][tid], R.keep[1][tid], R.keep[2][tid]);
+        r = R.keep[3][tid]; g = R.keep[4][tid]; b = R.keep[5][tid];
+        t = R.keep[6][tid];
+        mi = __float_as_int(R.keep[7][tid]);
       } else {
         const V3<V> ov[1] = {{ro.x, ro.y, ro.z}}, Lv[1] = {{rL.x, rL.y, rL.z}};
         constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTri);
