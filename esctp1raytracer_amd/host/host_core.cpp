@@ -91,6 +91,12 @@ int esc_scene_add_geometry(esc_scene *scene, const float *vertex, int32_t n_vert
       return ESC_ERR_INVALID;
     }
   }
+  // the kernels' loops and the acceleration structure assume finite coordinates
+  for (int64_t i = 0; i < (int64_t)n_vertices * 3; i++)
+    if (!std::isfinite(vertex[i])) {
+      set_error("esc_scene_add_geometry: non-finite vertex coordinate");
+      return ESC_ERR_INVALID;
+    }
   esc::Geometry g;
   g.vertex.assign(vertex, vertex + (size_t)n_vertices * 3);
   if (n_normals > 0) g.normals.assign(normals, normals + (size_t)n_normals * 3);
@@ -109,6 +115,11 @@ int esc_scene_add_spheres(esc_scene *scene, const float *spheres_xyzr, const flo
     set_error("esc_scene_add_spheres: bad argument");
     return ESC_ERR_INVALID;
   }
+  for (int64_t i = 0; i < (int64_t)n_spheres * 4; i++)
+    if (!std::isfinite(spheres_xyzr[i])) {
+      set_error("esc_scene_add_spheres: non-finite centre or radius");
+      return ESC_ERR_INVALID;
+    }
   for (int32_t i = 0; i < n_spheres; i++) {
     esc::Sphere s{spheres_xyzr[4 * i], spheres_xyzr[4 * i + 1], spheres_xyzr[4 * i + 2],
                   spheres_xyzr[4 * i + 3]};

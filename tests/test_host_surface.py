@@ -159,6 +159,22 @@ def test_scene_build_introspect_roundtrip(esc):
         sc.add_geometry([[0, 0, 0]] * 3, [[0, 1, 3]], ol.WHITE)  # face index out of range
 
 
+def test_scene_rejects_bad_input(esc):
+    """out-of-range face indices and non-finite coordinates fail loudly at scene building"""
+    m = ol.material13(ka=(.5,) * 3, kd=(.5,) * 3)
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    sc = esc.Scene()
+    with pytest.raises(esc.EscError):
+        sc.add_geometry(v, np.array([[0, 1, 3]]), m)
+    bad = v.copy()
+    bad[1, 2] = np.nan
+    with pytest.raises(esc.EscError):
+        sc.add_geometry(bad, np.array([[0, 1, 2]]), m)
+    with pytest.raises(esc.EscError):
+        sc.add_spheres(np.array([[0, 0, 0, np.inf]], np.float32), m[None, :])
+    assert sc.info()["n_triangles"] == 0 and sc.info()["n_spheres"] == 0
+
+
 def test_camera_matches_reference_outputs(esc, golden_dir):
     with np.load(golden_dir + "/ref_pieces.npz") as f:
         z = {k: f[k] for k in f.files}
