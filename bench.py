@@ -59,8 +59,8 @@ def parse():
                          "quantised bytes k_shade writes (main.cpp:676-682; 4x fewer bytes over "
                          "xGMI, SURVEY.md 8(f)2).  auto = fp32 on one GPU, u8 when there is a gather")
     ap.add_argument("--cpu-rows", type=int, default=-1,
-                    help="rows of the frame the CPU baseline renders (0 = skip, -1 = as many as "
-                         "fit ~15 s of CPU work: 768 on c4, 34 on c5, all on c2/c3)")
+                    help="rows of the frame the CPU baseline renders (0 = skip, -1 = as many as a "
+                         "one-row-per-thread probe says fit ~12 s of CPU work)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo lets several ranks share one GPU to rehearse the N>1 path")
     ap.add_argument("--verify-rows", type=int, default=0,
@@ -133,29 +133,47 @@ def accel_leg(esc, r, st, cam, eye, W, H, shadows, steps, warmup, brute_frame, a
 
 
 def cpu_baseline(scene, eye, look, W, H, shadows, n_rows, gpu_frame):
-    """oracle on evenly spaced rows of the same frame, all host cores; also a free parity
-    spot-check of the GPU frame on those rows"""
+    """The CPU checker on evenly spaced rows of the same frame, all host cores -- its
+    eight-pixel packet build (oracle/rt_oracle_fast.c, AVX2, bit-equal to rt_oracle.c: SURVEY.md
+    8(d)'s cpu_fast stand-in for the host ISPC path) when the CPU has AVX2, else the scalar one.
+    n_rows < 0: a probe of one row per thread sizes the sample to ~12 s.  Also a free parity spot-check of
+    the GPU frame on those rows."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
 
     import oracle_lib as ol
 
     d = ol.OracleScene(ol.scene_from_product(scene))
-    rows = sorted({min(H - 1, int((i + 0.5) * H / n_rows)) for i in range(n_rows)})
     cores = host_cores()
+    packets = ol.oracle_fast() is not None
+
+    def spaced(n):
+        return sorted({min(H - 1, int((i + 0.5) * H / n)) for i in range(n)})
+
+    if n_rows < 0:
+        probe = spaced(cores)  # rows are the unit of parallelism: one per thread
+        t0 = time.perf_counter()
+        ol.oracle_render_rows(d, eye, look, W, H, probe, shadows=shadows, threads=cores,
+                              fast=True)
+        per_row = max((time.perf_counter() - t0) / len(probe), 1e-6)
+        n_rows = int(max(8, min(H, 12.0 / per_row)))
+    rows = spaced(n_rows)
     t0 = time.perf_counter()
-    img, cnt = ol.oracle_render_rows(d, eye, look, W, H, rows, shadows=shadows, threads=cores)
+    img, cnt = ol.oracle_render_rows(d, eye, look, W, H, rows, shadows=shadows, threads=cores,
+                                     fast=True)
     dt = time.perf_counter() - t0
     rays = cnt["primary_rays"] + cnt["shadow_rays"]
     same = None
     if gpu_frame is not None:
         g = gpu_frame[rows]
         same = bool(np.array_equal(g.view(np.uint32), img.view(np.uint32)))
+    how = ("oracle/rt_oracle_fast.c (8-pixel AVX2 packets, bit-equal to rt_oracle.c), gcc -O3 "
+           "-mavx2 -ffp-contract=off -fno-fast-math" if packets else
+           "oracle/rt_oracle.c (scalar), gcc -O2 -ffp-contract=off")
     return {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": f"{len(rows)} evenly spaced rows of the same {W}x{H} frame "
-                  f"({rays} rays, {dt:.1f} s); oracle/rt_oracle.c, gcc -O2 -ffp-contract=off, "
-                  f"row-parallel pthreads",
+                  f"({rays} rays, {dt:.1f} s); {how}, row-parallel pthreads",
         "seconds": dt,
     }, same
 
@@ -343,10 +361,7 @@ def main():
                                       "FMA as 2 flop and this kernel may not fuse (bit parity), so "
                                       "0.5 is the ceiling"},
         }
-        if world == 1 and a.cpu_rows < 0:
-            # bounded sample: ~3e9 ray-primitive tests per second on the box's 16 host cores
-            a.cpu_rows = int(max(8, min(H, 15 * 3e9 / (W * max(n_tri + n_sph, 1) * 1.7))))
-        if world == 1 and a.cpu_rows > 0:
+        if world == 1 and a.cpu_rows != 0:
             gpu_frame = None
             if not use_u8:
                 gpu_frame = local[0][:H * W * 3].cpu().numpy().reshape(H, W, 3)

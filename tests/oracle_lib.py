@@ -12,6 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+ORACLE_FAST_SO = os.path.join(ORACLE_DIR, "liboracle_fast.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_pieces.so")
 
 ORC_FACE_FIXED, ORC_FACE_HASH = 0, 1
@@ -94,6 +95,35 @@ def oracle():
         lib.orc_write_ppm.argtypes = [C.c_char_p, _F, C.c_int32, C.c_int32]
         _oracle = lib
     return _oracle
+
+
+_oracle_fast = None
+
+
+def have_avx2():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return " avx2" in f.read()
+    except OSError:
+        return False
+
+
+def oracle_fast():
+    """rt_oracle_fast.c: the same restatement eight pixels at a time (AVX2).  None when the
+    host CPU has no AVX2."""
+    global _oracle_fast
+    if _oracle_fast is None:
+        if not have_avx2():
+            return None
+        if not os.path.exists(ORACLE_FAST_SO):
+            build_oracle()
+        lib = C.CDLL(ORACLE_FAST_SO)
+        lib.orc_fast_render_row_list.argtypes = [
+            C.POINTER(orc_scene), C.POINTER(orc_camera), C.c_int32, C.c_int32,
+            C.POINTER(C.c_int32), C.c_int32, C.POINTER(orc_options), _F, C.POINTER(orc_counters),
+            C.c_int32]
+        _oracle_fast = lib
+    return _oracle_fast
 
 
 def have_ref():
@@ -267,17 +297,20 @@ def oracle_render(d, lookfrom, lookat, W, H, *, shadows=True, face_mode=ORC_FACE
 
 
 def oracle_render_rows(d, lookfrom, lookat, W, H, rows, *, shadows=True,
-                       face_mode=ORC_FACE_FIXED, fixed_face=0, seed=0, threads=1):
-    """rows: list of image rows -> (len(rows), W, 3) fp32 + counters"""
+                       face_mode=ORC_FACE_FIXED, fixed_face=0, seed=0, threads=1, fast=False):
+    """rows: list of image rows -> (len(rows), W, 3) fp32 + counters.  fast=True runs the
+    eight-pixel packet version (rt_oracle_fast.c; falls back to the scalar one without AVX2)."""
     osc = d if isinstance(d, OracleScene) else OracleScene(d)
     cam = oracle_camera(lookfrom, lookat, W, H)
     o = orc_options(1 if shadows else 0, face_mode, fixed_face, seed, ORC_QUIRK_ALL)
     rr = np.ascontiguousarray(rows, np.int32)
     img = np.zeros((len(rr), W, 3), np.float32)
     cnt = orc_counters()
-    oracle().orc_render_row_list(C.byref(osc.c), C.byref(cam), W, H,
-                                 rr.ctypes.data_as(C.POINTER(C.c_int32)), len(rr), C.byref(o),
-                                 fp(img), C.byref(cnt), threads)
+    lib_fast = oracle_fast() if fast else None
+    fn = lib_fast.orc_fast_render_row_list if lib_fast is not None else \
+        oracle().orc_render_row_list
+    fn(C.byref(osc.c), C.byref(cam), W, H, rr.ctypes.data_as(C.POINTER(C.c_int32)), len(rr),
+       C.byref(o), fp(img), C.byref(cnt), threads)
     return img, {"primary_rays": cnt.primary_rays, "hit_pixels": cnt.hit_pixels,
                  "shadow_rays": cnt.shadow_rays, "anyhit_tests": cnt.anyhit_tests}
 
