@@ -22,11 +22,17 @@ for seed in range(n_seeds):
         tri[:, :, 1] = np.round(tri[:, :, 1])
     col = np.array([.5, .5, .5] * 2 + [0] * 6 + [10.], np.float32)
     sc.add_geometry(tri.reshape(-1, 3), np.arange(3 * n_tri).reshape(-1, 3), col)
-    for _ in range(int(rng.integers(1, 4))):
+    n_lights = int(rng.integers(1, 4))
+    two_faces = seed % 4 == 1  # two-face lights: hashed face choice, 2 sample points per light
+    for _ in range(n_lights):
         p0 = rng.uniform(-spread, spread, 3) + np.array([0, spread, 0])
         lt = np.stack([p0, p0 + rng.normal(0, 0.3, 3), p0 + rng.normal(0, 0.3, 3)]).astype(np.float32)
         m = col.copy(); m[9:12] = (9, 8, 7)
-        sc.add_geometry(lt, np.array([[0, 1, 2]]), m)
+        if two_faces:
+            lt = np.concatenate([lt, lt + rng.normal(0, 0.5, (1, 3)).astype(np.float32)])
+            sc.add_geometry(lt, np.array([[0, 1, 2], [3, 4, 5]]), m)
+        else:
+            sc.add_geometry(lt, np.array([[0, 1, 2]]), m)
     if n_sph:
         sph = np.concatenate([rng.uniform(-spread, spread, (n_sph, 3)),
                               rng.uniform(0.01, 0.1 * spread, (n_sph, 1))], 1).astype(np.float32)
@@ -35,8 +41,9 @@ for seed in range(n_seeds):
     eye = rng.uniform(-1.5 * spread, 1.5 * spread, 3)
     look = rng.uniform(-0.3 * spread, 0.3 * spread, 3)
     cam = esc.Camera.for_image(tuple(eye), tuple(look), W, H)
-    a = r.render(cam, W, H)
-    b = r.render(cam, W, H, stage=esc.ESC_STAGE_BVH)
+    kw = {"face_mode": esc.ESC_FACE_HASH, "seed": seed} if two_faces else {}
+    a = r.render(cam, W, H, **kw)
+    b = r.render(cam, W, H, stage=esc.ESC_STAGE_BVH, **kw)
     nd = int((a.view(np.uint32) != b.view(np.uint32)).sum())
     if nd:
         bad += 1
