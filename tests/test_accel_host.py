@@ -209,3 +209,84 @@ def test_triangle_boxes_never_cull_an_accepted_hit():
     light = np.array([-0.5, 12.0, -9.5], np.float32)
     n = _conservative(a, tris, accept, _rays(None, 48, 36), light)
     assert n > 200
+
+
+def test_sphere_pads_hold_for_grazing_rays_from_far_away():
+    """The sphere pad is a proof (accel_build.cpp): aim rays from the far corners of the region
+    rays may start in at points just inside / outside each silhouette, where the fp32 discriminant
+    is pure cancellation, and check that every hit the oracle's arithmetic reports is still
+    reachable through the padded boxes."""
+    lib = oracle()
+    rng = np.random.default_rng(21)
+    sc = esc.Scene.synthetic("c4", 120)  # small spheres, r in [0.05, 0.2]
+    far = (11.0, 11.0, 5.5)              # inside the origin bounds of this scene, far from most
+    a = sc.build_accel(far, "spheres")
+    sph, _ = sc.spheres()
+    checked = grazing = 0
+    for o in (np.array(far, np.float32), np.array((-11.0, 0.2, -23.0), np.float32)):
+        for k, s in enumerate(sph):
+            c, r = s[:3].astype(np.float64), float(s[3])
+            to_c = c - o
+            dist = np.linalg.norm(to_c)
+            u = np.cross(to_c, rng.normal(size=3))
+            u /= np.linalg.norm(u)
+            for delta in (-1e-3, -1e-5, -1e-6, -1e-7, 0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3):
+                target = c + u * r * (1.0 + delta)  # a point next to the silhouette
+                d = (target - o)
+                d = (d / np.linalg.norm(d)).astype(np.float32)
+                d = (d / np.float32(np.sqrt(np.float32(np.dot(d, d))))).astype(np.float32)
+                t = C.c_float(FLT_MAX)
+                if lib.orc_intersect_sphere(fp(o), fp(d), fp(np.ascontiguousarray(s)), C.byref(t)):
+                    checked += 1
+                    grazing += delta > 0  # "hit" although aimed outside the sphere
+                    assert k in _walk(a, o, d, t.value), \
+                        f"sphere {k} culled: dist {dist:.1f}, delta {delta}"
+    assert checked > 500 and grazing > 20  # the rounded test does accept rays aimed outside
+
+
+def test_triangle_pads_hold_next_to_the_edges():
+    """rays from far away aimed at points just inside / outside triangle edges, at shallow but not
+    degenerate angles to the triangle's plane (>= 0.02 rad): every hit the oracle's mixed fp32/f64
+    arithmetic reports must be reachable through the padded boxes"""
+    lib = oracle()
+    rng = np.random.default_rng(22)
+    sc = esc.Scene.synthetic("c5", 8)  # 128 terrain triangles + the light
+    far = (11.0, 9.0, 5.0)
+    a = sc.build_accel(far, "triangles")
+    tris = []
+    for g in range(sc.info()["n_geometry"]):
+        G = sc.geometry(g)
+        for f in G["face_index"]:
+            tris.append(tuple(np.ascontiguousarray(G["vertex"][i]) for i in f))
+    checked = outside = 0
+    for k, T in enumerate(tris):
+        v0, v1, v2 = (x.astype(np.float64) for x in T)
+        n = np.cross(v1 - v0, v2 - v0)
+        n /= np.linalg.norm(n)
+        for _ in range(6):
+            w = rng.uniform(0.0, 1.0)
+            edge_pt = v0 + (v1 - v0) * w                      # a point on edge v0-v1
+            inward = np.cross(n, v1 - v0)
+            inward /= np.linalg.norm(inward)
+            if np.dot(inward, v2 - v0) < 0:
+                inward = -inward
+            for delta in (-1e-4, -1e-6, 0.0, 1e-6, 1e-4):
+                target = edge_pt + inward * delta              # delta < 0: just outside
+                theta = rng.uniform(0.02, 1.2)                 # angle between ray and plane
+                in_plane = np.cross(n, rng.normal(size=3))
+                in_plane /= np.linalg.norm(in_plane)
+                dirv = -(np.cos(theta) * in_plane + np.sin(theta) * n)
+                o = (target - dirv * rng.uniform(3.0, 25.0)).astype(np.float32)
+                # the pads are sized for rays that start inside the scene's origin bounds
+                if not (abs(o[0]) < 16 and -4 < o[1] < 16 and -28 < o[2] < 9):
+                    continue
+                d = (target - o.astype(np.float64))
+                d = (d / np.linalg.norm(d)).astype(np.float32)
+                d = (d / np.float32(np.sqrt(np.float32(np.dot(d, d))))).astype(np.float32)
+                t, u, v = C.c_float(FLT_MAX), C.c_float(0), C.c_float(0)
+                if lib.orc_intersect_triangle(fp(o), fp(d), fp(T[0]), fp(T[1]), fp(T[2]),
+                                              C.byref(t), C.byref(u), C.byref(v)):
+                    checked += 1
+                    outside += delta < 0
+                    assert k in _walk(a, o, d, t.value), f"triangle {k} culled (delta {delta})"
+    assert checked > 500
