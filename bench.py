@@ -353,7 +353,13 @@ def main():
                        "launches_timed": len(events), "rank": 0, "rows": my_rows},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_note": "algorithmic = fp32 framebuffer + scene tables (SURVEY.md "
+                                         "8(d)); measured traffic also holds the 16-byte hit record "
+                                         "per pixel that k_primary hands to k_shade (written and "
+                                         "read once: 2 x 132.7 MB at 4K), i.e. 366 MB expected, "
+                                         "373.7 MB measured; the kernels are VALU-bound, see "
+                                         "roofline_valu"},
             "roofline_valu": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TF,
                               "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
                               "note": "algorithmic flop (19/sphere test, 51/triangle test) of the "
