@@ -472,11 +472,16 @@ def test_bvh_camera_move_rebuilds(esc, renderer):
     assert renderer.accel_info()["builds"] - before == 2
 
 
-@pytest.mark.parametrize("config,W,H", [("c2", 1920, 1080), ("c3", 3840, 2160),
-                                        ("c4", 3840, 2160), ("c5", 7680, 4320)])
-def test_bvh_full_size_equals_brute_force(esc, renderer, config, W, H):
-    """BASELINE.json's sizes: every pixel of the BVH frame == the brute-force frame."""
+@pytest.mark.parametrize("config,W,H,bins", [("c2", 1920, 1080, True), ("c3", 3840, 2160, True),
+                                             ("c4", 3840, 2160, True), ("c5", 7680, 4320, True),
+                                             ("c4", 3840, 2160, False),
+                                             ("c5", 7680, 4320, False)])
+def test_bvh_full_size_equals_brute_force(esc, renderer, config, W, H, bins, monkeypatch):
+    """BASELINE.json's sizes: every pixel of the BVH frame == the brute-force frame, with the
+    screen / light bins and with the plain tree walk (ESC_BVH_BINS=0)."""
     import torch
+    if not bins:
+        monkeypatch.setenv("ESC_BVH_BINS", "0")
     sc = esc.Scene.synthetic(config)
     eye, look = esc.synthetic_view()
     renderer.upload(sc)
