@@ -1,4 +1,4 @@
-"""Developer timing loop: k_render variants on the BASELINE c4 workload (one process, interleaved
+"""Developer timing loop: brute-force stage x pixels-per-lane variants on the BASELINE c4 workload (one process, interleaved
 rounds, HIP events on the stream the kernels run on)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
