@@ -186,8 +186,10 @@ enum {
   ESC_STAGE_SMEM = 1, /* primitives broadcast through the scalar cache into SGPRs */
   ESC_STAGE_LDS = 2,  /* primitives staged in LDS chunks by the workgroup */
   ESC_STAGE_BVH = 3   /* opt-in acceleration structure (what the reference's --bvh flag meant to
-                         be, main.cpp:98-171,331-415): a bounding-volume tree culls primitives
-                         before the same exact tests run, so the image is the brute-force image.
+                         be, main.cpp:98-171,331-415): screen-space bins for primary rays,
+                         light-space bins for shadow rays and a bounding-volume tree behind both
+                         cull primitives before the same exact tests run, so the image is the
+                         brute-force image.  One kernel per frame.
                          Never chosen by AUTO: BASELINE's configs are brute force. */
 };
 
