@@ -751,7 +751,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   }
   int e = esc_launch_render(&p, stage, px, ctx->stream);
   if (e) {
-    set_error(std::string("k_render launch: ") + hipGetErrorString((hipError_t)e));
+    set_error(std::string("frame kernel launch (k_primary / k_shade): ") + hipGetErrorString((hipError_t)e));
     return ESC_ERR_HIP;
   }
   return ESC_OK;

@@ -159,7 +159,7 @@ template <typename Rec> struct SmemFetch {
   // Read through the CONSTANT address space: with a wave-uniform address hipcc then always
   // selects s_load, also behind barriers / fences, where its "is this global memory ever
   // written in the kernel?" analysis gives up and would fall back to per-lane global_load.
-  // The tables are written before the launch and never by k_render.
+  // The tables are written before the launch and never by the frame kernels.
   DEVINL Rec operator()(int k) const {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     typedef const u4 __attribute__((address_space(4))) *ConstPtr;

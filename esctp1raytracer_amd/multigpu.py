@@ -13,7 +13,7 @@ BASELINE c4 scene a floor row costs ~3x a sky row.
 import torch
 import torch.distributed as dist
 
-STRIP_ROWS = 8  # == the workgroup tile height of k_render (rt_device.h kTileH)
+STRIP_ROWS = 8  # == the workgroup tile height of the frame kernels (rt_device.h kTileH)
 
 
 def n_strips(H, strip_rows=STRIP_ROWS):

@@ -1,7 +1,7 @@
 """N>1 path on CPU: two gloo ranks split a frame into round-robin strips, gather to rank 0 and
 lay the frame out.  The per-rank pixels come from the CPU oracle here (the product has no CPU
 renderer), so this covers the partition, the padded gather and the assembly -- the exact host
-logic bench.py runs around k_render on N GPUs."""
+logic bench.py runs around the frame kernels on N GPUs."""
 import os
 import socket
 import sys

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -48,7 +49,7 @@ def test_struct_layouts_match_ispc_headers():
 def test_library_contains_gfx950_code_object():
     from esctp1raytracer_amd import _capi
     blob = open(_capi.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"k_render" in blob
+    assert b"gfx950" in blob and b"k_primary" in blob and b"k_shade" in blob
 
 
 def test_no_gpu_means_error_not_fallback(esc):
@@ -62,6 +63,21 @@ def test_no_gpu_means_error_not_fallback(esc):
     cam = esc.Camera.for_image(*esc.synthetic_view(), 64, 48)
     with pytest.raises(esc.EscError):
         esc.render_multi(sc, cam, 64, 48, 2)
+
+
+def test_bench_and_viewer_fail_loudly_without_a_gpu():
+    """no silent CPU path anywhere: bench.py and the viewer exit non-zero with a clear message"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
+    viewer = os.path.join(ROOT, "bin", "ESCViewer2021")
+    if os.path.exists(viewer):
+        v = subprocess.run([viewer, "--scene", "c2", "-w", "64,48"], capture_output=True,
+                           text=True, timeout=120)
+        assert v.returncode != 0 and "no CPU fallback" in (v.stderr + v.stdout)
 
 
 def test_product_does_not_link_or_import_the_oracle():
