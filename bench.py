@@ -89,7 +89,7 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def accel_leg(esc, r, st, cam, eye, W, H, shadows, steps, warmup, brute_frame, alg_bytes):
+def accel_leg(esc, r, st, cam, eye, look_at, W, H, shadows, steps, warmup, brute_frame, alg_bytes):
     """The same frame through ESC_STAGE_BVH (opt-in like the reference's --bvh):
     tree build timed apart from the render (as main.cpp:569-579 does), K frames between HIP
     events on the render stream, and EVERY fp32 value compared with the brute-force frame."""
@@ -116,11 +116,36 @@ def accel_leg(esc, r, st, cam, eye, W, H, shadows, steps, warmup, brute_frame, a
     wall_ms = (time.perf_counter() - t0) * 1e3 / steps
     cnt = r.counters()
     ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    rays = (cnt["primary_rays"] + cnt["shadow_rays"]) / steps
     differing = int((buf.view(torch.int32) != brute_frame[:H * W * 3].view(torch.int32)).sum().item())
+    # a camera that moves every frame: the per-camera constants (k_prepare_*) and the screen bins
+    # are redone each time, the tree and the light bins are not (they belong to the scene)
+    import math
+    mv, cams = [], []
+    for i in range(steps):
+        ang = 2 * math.pi * i / max(steps, 1)
+        e = (eye[0] + 0.3 * math.cos(ang), eye[1] + 0.1 * math.sin(ang), eye[2] + 0.3 * math.sin(ang))
+        cams.append(esc.Camera.for_image(e, look_at, W, H))
+    for c in cams:
+        with torch.cuda.stream(st):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            r.render_rows(c, W, H, 0, H, out_f32=buf, shadows=shadows, stage=esc.ESC_STAGE_BVH)
+            e1.record(st)
+        mv.append((e0, e1))
+    st.synchronize()
+    ms_moving = sum(a.elapsed_time(b) for a, b in mv) / len(mv)
+    chk = torch.zeros_like(buf)
+    with torch.cuda.stream(st):
+        r.render_rows(cams[-1], W, H, 0, H, out_f32=chk, shadows=shadows)  # brute force, same camera
+    st.synchronize()
+    moving_same = int((buf.view(torch.int32) != chk.view(torch.int32)).sum().item()) == 0
+    rays = (cnt["primary_rays"] + cnt["shadow_rays"]) / steps
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return {"stage": "bvh", "value": rays / (ms * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms,
             "ms_per_step_wall": wall_ms,  # host clock over the same K frames, launches included
+            "ms_per_step_moving_camera": ms_moving,  # new camera position every frame
+            "moving_camera_last_frame_identical_to_brute_force": moving_same,
             "steps": steps, "timing": "HIP events around the whole frame: memset + k_bin_primary + k_shade<BVH> (closest hit and shading in one kernel)",
             "fp32_values_differing_from_brute_force": differing,
             "identical_to_brute_force": differing == 0,
@@ -376,7 +401,7 @@ def main():
             out["gpu_vs_cpu"] = out["value"] / cb["value"]
             out["parity_sample_rows_bit_exact"] = same
         if world == 1 and a.stage != "bvh" and not a.no_accel and not use_u8:
-            out["accel"] = accel_leg(esc, r, st, cam, eye, W, H, shadows, a.steps, a.warmup,
+            out["accel"] = accel_leg(esc, r, st, cam, eye, look, W, H, shadows, a.steps, a.warmup,
                                      local[0], alg_bytes)
         if world > 1 and a.verify_rows > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
