@@ -627,3 +627,25 @@ def test_bvh_random_scenes(esc, renderer, seed):
     assert_bit_equal(brute, ref, f"random/{seed}/brute")
     bvh = renderer.render(cam, W, H, stage=esc.ESC_STAGE_BVH)
     assert_bit_equal(bvh, ref, f"random/{seed}/bvh")
+
+
+def test_bvh_strips_equal_full_frame(esc, renderer):
+    """the multi-GPU partition under ESC_STAGE_BVH: 8-row strips sit on the screen bins' 8-row
+    grid, every rank's strips reproduce the rows of the full frame"""
+    import torch
+    from esctp1raytracer_amd import multigpu
+    sc, d = synthetic_dict(esc, "c3", 300)
+    eye, look = esc.synthetic_view()
+    W, H = 200, 93
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    ref = ol.oracle_render(d, eye, look, W, H, threads=8)
+    world = 3
+    max_rows = multigpu.max_local_rows(H, world)
+    gathered = torch.zeros(world, max_rows * W * 3, dtype=torch.float32, device="cuda:0")
+    for rank in range(world):
+        renderer.render_strips(cam, W, H, rank, world, out_f32=gathered[rank],
+                               stage=esc.ESC_STAGE_BVH)
+    renderer.synchronize()
+    frame = multigpu.assemble_frame_torch(gathered, world, W, H).cpu().numpy()
+    assert_bit_equal(frame, ref, "bvh strips")
