@@ -54,6 +54,7 @@ void esc_scene_free(esc_scene *scene);
 /* Append one tracer::scene::Geometry (scene.h:20-31): de-indexed vertices, optional
  * per-vertex normals (n_normals == 0 => none), face_index triples into `vertex`.
  * The geometry is a light source iff dot(ke,ke) > 0 (sceneloader.cpp:63-64,102-104).
+ * Coordinates must be finite and face indices in range (ESC_ERR_INVALID otherwise).
  * Returns the new geomID (>= 0) or a negative error. */
 int esc_scene_add_geometry(esc_scene *scene, const float *vertex, int32_t n_vertices,
                            const float *normals, int32_t n_normals, const uint32_t *face_index,
