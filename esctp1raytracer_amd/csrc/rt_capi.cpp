@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -630,6 +631,14 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     set_error("render: pixels_per_lane must be 0 (auto), 1, 2 or 4");
     return ESC_ERR_INVALID;
   }
+  // a degenerate camera (lookfrom == lookat, zero aspect: NaN / inf basis vectors) would make
+  // every ray NaN; the kernels' filters are written for finite inputs, so it is refused
+  for (int k = 0; k < 3; k++)
+    if (!std::isfinite(cam->origin[k]) || !std::isfinite(cam->lower_left_corner[k]) ||
+        !std::isfinite(cam->horizontal[k]) || !std::isfinite(cam->vertical[k])) {
+      set_error("render: camera is not finite (lookfrom == lookat, or a zero / NaN aspect?)");
+      return ESC_ERR_INVALID;
+    }
   if (n_local_rows == 0) return ESC_OK;
   HIP_TRY(hipSetDevice(ctx->device));
 

@@ -649,3 +649,14 @@ def test_bvh_strips_equal_full_frame(esc, renderer):
     renderer.synchronize()
     frame = multigpu.assemble_frame_torch(gathered, world, W, H).cpu().numpy()
     assert_bit_equal(frame, ref, "bvh strips")
+
+
+def test_degenerate_camera_is_refused(esc, renderer):
+    """lookfrom == lookat gives a NaN camera basis: every ray would be NaN (the reference renders
+    garbage); the render entry points refuse it instead, in every mode"""
+    sc, d = synthetic_dict(esc, "c3", 100)
+    renderer.upload(sc)
+    cam = esc.Camera.for_image((0, 2, -8), (0, 2, -8), 64, 48)
+    for stage in (esc.ESC_STAGE_AUTO, esc.ESC_STAGE_LDS, esc.ESC_STAGE_BVH):
+        with pytest.raises(esc.EscError):
+            renderer.render(cam, 64, 48, stage=stage)
