@@ -253,21 +253,34 @@ def main():
             frame = torch.zeros(H * W * 3, dtype=ch_dtype, device=dev)
             r2 = esc.Renderer(local_rank, stream=st2)
     buf_free = [None] * n_buf  # event: the gather that last read local[b] has finished
+    # N>1: consecutive frames also alternate between TWO render contexts / streams.  A rank's
+    # share of the frame is a small grid (N=8: 2,040 + 4,080 workgroups) whose last workgroups
+    # leave most of the chip idle; with the next frame already queued on the other stream those
+    # CUs have work (measured on one GPU rendering rank 0's share of 8: 2.89 -> 2.35 ms per frame,
+    # ideal 18.4/8 = 2.30).  N=1 keeps one stream so kernel.avg_ms is an undisturbed duration.
+    renderers, streams = [r], [st]
+    if world > 1:
+        stb = torch.cuda.Stream(device=dev)
+        rb = esc.Renderer(local_rank, stream=stb)
+        rb.upload(scene)
+        renderers.append(rb)
+        streams.append(stb)
 
     events = []
 
     def step(i, timed):
         b = i % n_buf
-        with torch.cuda.stream(st):
+        rr, ss = renderers[b % len(renderers)], streams[b % len(streams)]
+        with torch.cuda.stream(ss):
             if buf_free[b] is not None:
-                st.wait_event(buf_free[b])
+                ss.wait_event(buf_free[b])
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(st)
-            r.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
-                            out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows,
-                            stage=stage)
-            e1.record(st)
+            e0.record(ss)
+            rr.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
+                             out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows,
+                             stage=stage)
+            e1.record(ss)
             if timed:
                 events.append((e0, e1))
         if world > 1:
@@ -283,7 +296,8 @@ def main():
                 buf_free[b] = ev
 
     def fence():
-        st.synchronize()
+        for ss in streams:
+            ss.synchronize()
         if st2 is not None:
             st2.synchronize()
         torch.cuda.synchronize()
@@ -294,14 +308,18 @@ def main():
     for i in range(a.warmup):
         step(i, False)
     fence()
-    r.reset_counters()
+    for rr in renderers:
+        rr.reset_counters()
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, True)
     fence()
     elapsed = time.perf_counter() - t0
-    cnt = r.counters()  # rays of exactly the K timed frames
+    cnt = renderers[0].counters()  # rays of exactly the K timed frames
+    for rr in renderers[1:]:
+        for k, v in rr.counters().items():
+            cnt[k] += v
 
     # one un-pipelined frame: launch -> complete frame resident on rank 0
     fence()
@@ -320,6 +338,9 @@ def main():
     elapsed = float(t.item())
     primary, shadow, anyhit, hits, lane_tests = (float(x) for x in c.tolist())
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
+    # N>1 keeps two frames in flight, so an event pair also spans time given to the other frame;
+    # the rooflines there use this rank's throughput time per frame instead
+    roof_ms = kernel_ms if world == 1 else elapsed / a.steps * 1e3
 
     if rank == 0:
         rays = primary + shadow
@@ -328,7 +349,7 @@ def main():
         frame_bytes = my_rows * W * 3 * local[0].element_size()
         scene_bytes = n_sph * 32 + n_tri * 112 + (info["n_geometry"] + n_sph) * 64
         alg_bytes = frame_bytes + scene_bytes
-        gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        gbs = alg_bytes / (roof_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if world == 1 and a.config == "c4" and not a.prims and os.path.exists(tpath):
@@ -338,7 +359,7 @@ def main():
         closest_flop = (primary / a.steps) * share * (n_tri * F_TRI + n_sph * F_SPHERE)
         f_any = (n_tri * F_TRI + n_sph * F_SPHERE) / max(n_tri + n_sph, 1)
         anyhit_flop = (anyhit / a.steps) * share * f_any
-        tf = (closest_flop + anyhit_flop) / (kernel_ms * 1e-3) / 1e12
+        tf = (closest_flop + anyhit_flop) / (roof_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/sec + frame ms, 3840x2160 / 10k spheres, at 1/2/4/8 MI355X",
             "value": rays / elapsed / 1e6,
@@ -363,7 +384,8 @@ def main():
                 "gather": ("none (1 GPU)" if world == 1 else
                            f"{'RCCL' if a.backend == 'nccl' else 'gloo'} gather of "
                            f"{'u8' if use_u8 else 'fp32'} RGB strips to rank 0 + k_assemble_strips, "
-                           f"on a second stream overlapping the next frame's render"),
+                           f"on a second stream overlapping the next frame's render; consecutive "
+                           f"frames alternate between two render streams"),
                 "stage": a.stage,
                 "rays_per_frame": rays / a.steps,
                 "primary_rays_per_frame": primary / a.steps,
@@ -373,7 +395,9 @@ def main():
                 "anyhit_tests_per_frame": anyhit / a.steps,
                 "shadow_lane_efficiency": (anyhit / lane_tests) if lane_tests else None,
             },
-            "kernel": {"name": "k_primary + k_shade (one frame = both, back to back on one stream)",
+            "kernel": {"name": "k_primary + k_shade (one frame = both, back to back on one stream)"
+                               + ("" if world == 1 else "; N>1: two frames are in flight on two "
+                                  "streams, so this duration includes time shared with the other frame"),
                        "avg_ms": kernel_ms,
                        "launches_timed": len(events), "rank": 0, "rows": my_rows},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
