@@ -294,3 +294,25 @@ def test_host_code_under_sanitizers(tmp_path, golden_dir):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "failures=0" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr
     assert "runtime error" not in r.stderr
+
+
+def test_strip_partition_properties(esc):
+    """the C ABI's strip arithmetic against the Python mirror, for arbitrary heights and rank
+    counts: every row belongs to exactly one rank, rank 0 never holds fewer rows than another"""
+    from hypothesis import given, settings, strategies as st_
+
+    from esctp1raytracer_amd import multigpu
+
+    @settings(max_examples=200, deadline=None)
+    @given(H=st_.integers(1, 9000), world=st_.integers(1, 64), k=st_.integers(1, 8))
+    def check(H, world, k):
+        S = 8 * k
+        rows = [esc.strip_local_rows(H, S, r, world) for r in range(world)]
+        assert rows == [multigpu.local_rows(H, r, world, S) for r in range(world)]
+        assert sum(rows) == H and max(rows) == rows[0] == multigpu.max_local_rows(H, world, S)
+        seen = sorted(k2 for r in range(world) for k2 in multigpu.strips_of_rank(H, r, world, S))
+        assert seen == list(range(multigpu.n_strips(H, S)))
+
+    check()
+    with pytest.raises(esc.EscError):
+        esc.strip_local_rows(100, 12, 0, 2)  # strip height must be a multiple of 8
