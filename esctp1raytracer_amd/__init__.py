@@ -168,6 +168,12 @@ class FlatScene:
         self.lights = self._lib.esc_flat_lights(self._h, C.byref(n))
         self.num_lights = n.value
 
+    def check(self):
+        """esc_check_flat: host-only validation of what `trace` would stage (raises EscError)."""
+        check(self._lib.esc_check_flat(self.num_triangles, self.triangles, self.num_lights,
+                                       self.lights, self.num_light_triangles,
+                                       self.light_triangles))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -126,6 +126,8 @@ SIGNATURES = {
     "esc_upload_scene": (C.c_int, [_P, _P]),
     "esc_upload_flat": (C.c_int, [_P, C.c_int32, C.POINTER(ispc_triangle), C.c_int32,
                                   C.POINTER(ispc_light), C.c_int32, C.POINTER(ispc_triangle)]),
+    "esc_check_flat": (C.c_int, [C.c_int32, C.POINTER(ispc_triangle), C.c_int32,
+                                 C.POINTER(ispc_light), C.c_int32, C.POINTER(ispc_triangle)]),
     "esc_render_rows": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.POINTER(esc_render_options), _P, _P]),
     "esc_render_strips": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32, C.c_int32,

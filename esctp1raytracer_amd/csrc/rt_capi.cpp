@@ -183,6 +183,11 @@ int stage_scene(const esc_scene &scene, Staged &s) {
   }
   for (size_t li : scene.light_sources) { // main.cpp:740-748
     const esc::Geometry &g = scene.geometry[li];
+    if (g.n_faces() == 0) {
+      set_error("light geometry has no faces: light.vertex[faceID] (main.cpp:748) has nothing "
+                "to sample");
+      return ESC_ERR_INVALID;
+    }
     if (g.n_faces() > g.n_vertices()) {
       set_error("light geometry has more faces than vertices: light.vertex[faceID] "
                 "(main.cpp:748) would read out of range");
@@ -237,6 +242,11 @@ int stage_flat(int32_t nt, const ispc_triangle *tris, int32_t nl, const ispc_lig
     const ispc_light &L = lights[li];
     esc::DevLight D;
     D.first_point = (int)(s.light_points.size() / 4);
+    if (L.num_light_faces < 1 || !L.light_faces) {
+      // the face draw of main.cpp:743-748 is `% face count`; an empty light has no sample point
+      set_error("ispc_light.num_light_faces must be >= 1 and light_faces non-null");
+      return ESC_ERR_INVALID;
+    }
     D.n_faces = L.num_light_faces;
     // the scalar path's light.vertex[k], k < n_faces, is corner k%3 of light face k/3
     for (int k = 0; k < L.num_light_faces; k++) {
@@ -585,6 +595,20 @@ int esc_scene_build_accel(const esc_scene *scene, const float origin[3], int32_t
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   return ESC_OK;
+}
+
+int esc_check_flat(int32_t num_triangles, const ispc_triangle *triangles, int32_t num_lights,
+                   const ispc_light *lights, int32_t num_light_triangles,
+                   const ispc_triangle *light_triangles) {
+  if (num_triangles < 0 || num_lights < 0 || num_light_triangles < 0 ||
+      (num_triangles && !triangles) || (num_lights && !lights) ||
+      (num_light_triangles && !light_triangles)) {
+    set_error("esc_check_flat: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  Staged s;
+  return stage_flat(num_triangles, triangles, num_lights, lights, num_light_triangles,
+                    light_triangles, s);
 }
 
 int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle *triangles,

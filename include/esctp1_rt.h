@@ -165,11 +165,15 @@ void esc_new_ispc_cam(ispc_cam *cam, const float lookfrom[3], const float lookat
  * because the replaced function returns void.  Multi-face lights use the counter-based
  * face choice below with seed 0.  $ESC_TRACE_STAGE=bvh renders through the opt-in
  * acceleration structure (ESC_STAGE_BVH below) -- same image.
+ * The reference's C++ host gets the `ispc::trace(..., ispc_cam &, ...)` form of this
+ * declaration from include/trace_ispc.h (the replacement for the ISPC-generated header).
  * ---------------------------------------------------------------------------------- */
+#ifndef ESC_NO_TRACE_DECL /* include/trace_ispc.h declares it with `ispc_cam &` in namespace ispc */
 void trace(int32_t image_width, int32_t image_height, ispc_cam *cam, int32_t num_triangles,
            ispc_triangle triangles[], int32_t num_lights, ispc_light lights[],
            int32_t num_light_triangles, ispc_triangle light_triangles[], float *return_image,
            int32_t debug, int32_t test);
+#endif
 
 /* ------------------------------------------------------------------------------------
  * Extended entry points (persistent device state, row bands, device-resident output)
@@ -235,6 +239,14 @@ int esc_upload_scene(esc_context *ctx, const esc_scene *scene);
 int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle *triangles,
                     int32_t num_lights, const ispc_light *lights, int32_t num_light_triangles,
                     const ispc_triangle *light_triangles);
+
+/* Host-only check of the arrays `trace` / esc_upload_flat would stage (no GPU needed): geom ids
+ * >= 0, every light with >= 1 face and a non-null light_faces whose entries index
+ * light_triangles[].  It cannot detect a DANGLING light_faces pointer -- the reference's own
+ * flatten_scene_ispc leaves one (flatten_iscp.cpp:39,103); use esc_flatten_ispc instead. */
+int esc_check_flat(int32_t num_triangles, const ispc_triangle *triangles, int32_t num_lights,
+                   const ispc_light *lights, int32_t num_light_triangles,
+                   const ispc_triangle *light_triangles);
 
 /* == the row loop main.cpp:628-636 restricted to rows [row_begin,row_end) of a W x H frame
  * (scan_row, main.cpp:28-30, is the row-granular seam).  Asynchronous on the context's

@@ -389,3 +389,55 @@ def load_dump(name_or_path):
     d = scene_dict(geometry)
     assert d["light_sources"] == list(z["light_sources"])
     return d
+
+
+# --------------------------------------------------------------------------------------
+# SURVEY.md 8(d) "triangle-parity companions": a sphere config re-expressed with the
+# reference's ONLY primitive (ray_triangle.h:7-57) -- every sphere becomes a tessellated
+# icosahedron, one geometry per sphere, rendered through the reference-pinned triangle path.
+# --------------------------------------------------------------------------------------
+def _icosphere(subdiv):
+    """unit icosphere: (V,3) float64 vertices, (F,3) int faces (20 * 4**subdiv faces)"""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t),
+         (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4),
+         (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9),
+         (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v), np.array(f, np.int64)
+
+
+def icosphere_twin(d, subdiv, smooth_normals=False):
+    """scene dict with spheres -> scene dict with triangles only: sphere k (centre c, radius r,
+    material m) becomes geometry n_geometry + k, an icosphere of 20 * 4**subdiv faces with
+    de-indexed vertices (3 per face, like sceneloader.cpp:73-98) and optionally per-vertex
+    normals (exercises quirk S1 on every one of them)."""
+    uv, uf = _icosphere(subdiv)
+    geometry = list(d["geometry"])
+    corners = uv[uf.reshape(-1)]  # (F*3, 3) unit directions, face by face
+    fi = np.arange(len(corners), dtype=np.uint32).reshape(-1, 3)
+    for k in range(len(d["spheres"])):
+        cx, cy, cz, r = (float(x) for x in d["spheres"][k])
+        vert = (corners * r + np.array([cx, cy, cz])).astype(np.float32)
+        g = {"vertex": vert, "face_index": fi.copy(), "material": d["sphere_materials"][k].copy()}
+        if smooth_normals:
+            n = corners.astype(np.float32)
+            s = np.sqrt((n * n).sum(axis=1, dtype=np.float32), dtype=np.float32)
+            g["normals"] = (n / s[:, None]).astype(np.float32)
+        geometry.append(g)
+    return scene_dict(geometry)

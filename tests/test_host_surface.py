@@ -239,6 +239,34 @@ def test_flatten_ispc(esc):
         esc.Scene.synthetic("c2").flatten_ispc()  # spheres have no ispc_triangle form
 
 
+def test_check_flat_rejects_what_the_kernels_could_not_survive(esc):
+    """esc_check_flat (the staging half of `trace`, no GPU): a light without faces would reach
+    `hash % n_faces` on the device; out-of-range face indices and negative geom ids
+    would index outside the tables."""
+    flat = ol.scene_to_product(ol.load_dump("CornellBox-Original")).flatten_ispc(False)
+    flat.check()
+    L = flat.lights[0]
+    keep = (L.num_light_faces, L.light_faces[0], flat.triangles[3].geom_id)
+    for bad in (0, -1):
+        L.num_light_faces = bad
+        with pytest.raises(esc.EscError, match="num_light_faces"):
+            flat.check()
+    L.num_light_faces = keep[0]
+    L.light_faces[0] = flat.num_light_triangles  # one past the end
+    with pytest.raises(esc.EscError, match="out of range"):
+        flat.check()
+    L.light_faces[0] = keep[1]
+    flat.triangles[3].geom_id = -2
+    with pytest.raises(esc.EscError, match="geom_id"):
+        flat.check()
+    flat.triangles[3].geom_id = keep[2]
+    flat.check()
+    # the scene path cannot even hold a light without faces: add_geometry refuses it
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    with pytest.raises(esc.EscError):
+        esc.Scene().add_geometry(v, np.zeros((0, 3), np.uint32), ol.material13(ke=(5, 5, 5)))
+
+
 # ------------------------------------------------------------------ PPM (main.cpp:658-689)
 def test_ppm_writer_equals_reference_format(esc, tmp_path):
     rng = np.random.default_rng(3)
