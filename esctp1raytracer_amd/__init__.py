@@ -13,11 +13,11 @@ import numpy as np
 
 from . import _capi
 from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_BVH, ESC_STAGE_LDS,
-                    ESC_STAGE_SMEM, EscError, check)
+                    ESC_RENDER_EXACT_ONLY, ESC_STAGE_SMEM, EscError, check)
 
 __all__ = ["Scene", "Camera", "Renderer", "FlatScene", "render_multi", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
            "EscError", "ESC_FACE_FIXED", "ESC_FACE_HASH", "ESC_STAGE_AUTO", "ESC_STAGE_SMEM",
-           "ESC_STAGE_LDS", "ESC_STAGE_BVH", "version"]
+           "ESC_STAGE_LDS", "ESC_STAGE_BVH", "ESC_RENDER_EXACT_ONLY", "version"]
 
 
 def _f32(a, shape=None):
@@ -210,9 +210,10 @@ def synthetic_view():
     return eye, look
 
 
-def _options(shadows, face_mode, fixed_face, seed, stage, px=0):
+def _options(shadows, face_mode, fixed_face, seed, stage, px=0, flags=0):
     o = _capi.esc_render_options()
     o.pixels_per_lane = px
+    o.flags = flags
     o.shadows = 1 if shadows else 0
     o.face_mode = face_mode
     o.fixed_face = fixed_face
@@ -262,7 +263,7 @@ class Renderer:
 
     def render_rows(self, camera, W, H, row_begin, row_end, out_f32=None, out_u8=None, *,
                     shadows=True, face_mode=ESC_FACE_FIXED, fixed_face=0, seed=0,
-                    stage=ESC_STAGE_AUTO, px=0):
+                    stage=ESC_STAGE_AUTO, px=0, flags=0):
         """Asynchronous band render into DEVICE buffers (torch tensors or raw pointers),
         band-local layout ((h - row_begin) * W + w) * 3."""
         n = (row_end - row_begin) * W * 3
@@ -278,7 +279,7 @@ class Renderer:
                 return C.c_void_p(buf.data_ptr())
             return C.c_void_p(int(buf))
 
-        o = _options(shadows, face_mode, fixed_face, seed, stage, px)
+        o = _options(shadows, face_mode, fixed_face, seed, stage, px, flags)
         check(self._lib.esc_render_rows(self._h, C.byref(camera.c), W, H, row_begin, row_end,
                                         C.byref(o), ptr(out_f32, 4), ptr(out_u8, 1)))
 
@@ -296,13 +297,13 @@ class Renderer:
 
     def render_strips(self, camera, W, H, first_strip, strip_stride, out_f32=None, out_u8=None, *,
                       strip_rows=8, shadows=True, face_mode=ESC_FACE_FIXED, fixed_face=0, seed=0,
-                      stage=ESC_STAGE_AUTO, px=0):
+                      stage=ESC_STAGE_AUTO, px=0, flags=0):
         """Rank `first_strip` of `strip_stride`: renders strips first, first+stride, ... of
         `strip_rows` rows (counted from h = 0) into device buffers, rows packed in ascending h.
         Returns the number of rows rendered."""
         rows = strip_local_rows(H, strip_rows, first_strip, strip_stride)
         n = rows * W * 3
-        o = _options(shadows, face_mode, fixed_face, seed, stage, px)
+        o = _options(shadows, face_mode, fixed_face, seed, stage, px, flags)
         check(self._lib.esc_render_strips(self._h, C.byref(camera.c), W, H, strip_rows,
                                           first_strip, strip_stride, C.byref(o),
                                           self._dev_ptr(out_f32, n * 4), self._dev_ptr(out_u8, n)))
@@ -316,12 +317,12 @@ class Renderer:
             bytes_per_pixel, self._dev_ptr(frame, W * H * bytes_per_pixel)))
 
     def render(self, camera, W, H, *, want_u8=False, shadows=True, face_mode=ESC_FACE_FIXED,
-               fixed_face=0, seed=0, stage=ESC_STAGE_AUTO, px=0):
+               fixed_face=0, seed=0, stage=ESC_STAGE_AUTO, px=0, flags=0):
         """Whole frame into host numpy arrays (synchronous): fp32 (H, W, 3), h = 0 bottom row,
         and optionally the PPM-quantised bytes."""
         img = np.zeros((H, W, 3), np.float32)
         u8 = np.zeros((H, W, 3), np.uint8) if want_u8 else None
-        o = _options(shadows, face_mode, fixed_face, seed, stage, px)
+        o = _options(shadows, face_mode, fixed_face, seed, stage, px, flags)
         check(self._lib.esc_render_frame_host(
             self._h, C.byref(camera.c), W, H, C.byref(o), _fp(img),
             u8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_u8 else None))

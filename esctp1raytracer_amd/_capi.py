@@ -26,6 +26,7 @@ ESC_STAGE_SMEM = 1
 ESC_STAGE_LDS = 2
 ESC_STAGE_BVH = 3
 ESC_MATERIAL_FLOATS = 13
+ESC_RENDER_EXACT_ONLY = 1
 
 
 class EscError(RuntimeError):
@@ -65,7 +66,7 @@ class ispc_cam(C.Structure):  # ispc_helpers.h:59-65
 class esc_render_options(C.Structure):
     _fields_ = [("shadows", C.c_int32), ("face_mode", C.c_int32), ("fixed_face", C.c_int32),
                 ("stage", C.c_int32), ("seed", C.c_uint64), ("pixels_per_lane", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 class esc_counters(C.Structure):

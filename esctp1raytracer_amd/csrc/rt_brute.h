@@ -441,6 +441,107 @@ DEVINL void closest_sph_primary_pk(Fetch rec, int n, int base, const V3<v2f> &d,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// FILTERS: cheap conservative stand-ins for the reference's sphere discriminant.
+//
+// The reference arithmetic (no FMA, fixed order) costs 7 fp32 operations per
+// primary (ray, sphere) pair after hoisting and 16 per shadow pair, and all of them but a handful
+// per ray end in `disc < 0 -> miss`.  The hot loops therefore evaluate a cheaper expression q'
+// with FUSED multiply-adds -- 4 operations per primary pair, 8 per shadow pair -- built so that
+//
+//        the reference's fp32 evaluation does not reject at `disc < 0`   ==>   q' >= 0,
+//
+// and run the reference arithmetic itself (unchanged, on the exact records) for every batch of 8
+// spheres in which any lane has q' >= 0.  Accepts, t2 and the index order of ties are therefore
+// exactly the reference's: q' decides only WHETHER the exact code runs, never a result.
+// u = 2^-24, inputs finite with |coordinates| < 2^60, ray directions unit to a few ulp
+// (they come out of normalize()).
+//
+// Primary pairs (oc hoisted, A = |ocx|+|ocy|+|ocz|):  reference b = fl-dot(oc,d) and filter
+//   b' = fma(ocz,dz,fma(ocy,dy,fl(ocx dx))) are both within 3.01u A of the real dot product, so
+//   b^2 <= b'^2 + 12.1u A^2; with bb = fl(b b) <= b^2 (1+u) + 2^-149 the reference's
+//   "not disc < 0"  <=>  bb >= cc  implies  b'^2 - cc + 13.3u A^2 + 2^-149 >= 0.
+//   q' = fma(b',b',-ccm) (one rounding, sign-exact) with ccm = fl(cc - 2^-19 (A2f + r2) - 2^-120),
+//   A2f = fl(A)^2 >= A^2 (1-5u): the 32u margin covers the 13.3u above, the rounding of ccm
+//   itself (<= u (A^2 + r2)) and the rounding of A2f.
+//
+// Shadow pairs: rt_device.h DevSphPairF, proof next to sph_any_filter below.
+// ---------------------------------------------------------------------------------------
+struct SphF2 { // DevSphF seen as two aligned pairs: (ocx, ocy), (ocz, ccm)
+  v2f xy, zc;
+};
+
+// 4 spheres x 2 pixels: q'[i] = fma(b',b',-ccm_i), b' = fma(ocz,dz,fma(ocy,dy,ocx*dx))
+DEVINL void sph4_primary_filter_pk(const SphF2 (&s)[4], v2f dx, v2f dy, v2f dz, v2f (&q)[4]) {
+  asm("v_pk_mul_f32 %0, %[s0a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %1, %[s1a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %2, %[s2a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %3, %[s3a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %[s0a], %[y], %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %1, %[s1a], %[y], %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %2, %[s2a], %[y], %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %3, %[s3a], %[y], %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %0, %[s0b], %[z], %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %[s1b], %[z], %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %2, %[s2b], %[z], %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %3, %[s3b], %[z], %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %0, %0, %[s0b] op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+      "v_pk_fma_f32 %1, %1, %1, %[s1b] op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+      "v_pk_fma_f32 %2, %2, %2, %[s2b] op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+      "v_pk_fma_f32 %3, %3, %3, %[s3b] op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
+      : [x] "v"(dx), [y] "v"(dy), [z] "v"(dz), [s0a] "s"(s[0].xy), [s0b] "s"(s[0].zc),
+        [s1a] "s"(s[1].xy), [s1b] "s"(s[1].zc), [s2a] "s"(s[2].xy), [s2b] "s"(s[2].zc),
+        [s3a] "s"(s[3].xy), [s3b] "s"(s[3].zc));
+}
+
+// any q' >= 0 among 8 values?  raw-bit test: non-negative floats (and +NaN) are >= 0 as ints;
+// a q' of -0 cannot occur (an exactly-zero fma result is +0 in round-to-nearest)
+DEVINL int max_bits8(const v2f (&q)[4], int m) {
+  m = max3i(m, __float_as_int(q[0].x), __float_as_int(q[0].y));
+  m = max3i(m, __float_as_int(q[1].x), __float_as_int(q[1].y));
+  m = max3i(m, __float_as_int(q[2].x), __float_as_int(q[2].y));
+  return max3i(m, __float_as_int(q[3].x), __float_as_int(q[3].y));
+}
+
+// SMEM + 2 pixels per lane: the filter over 8 spheres per step; a step with a candidate re-reads
+// its 8 EXACT records and runs the reference arithmetic on them (test_sph_primary, above).
+// n is a multiple of 8 (the caller peels the rest through the exact loop).
+template <typename FetchF, typename FetchE>
+DEVINL void closest_sph_primary_filter(FetchF recf, FetchE rece, int n, int base, const V3<v2f> &d,
+                                       Hit (&h)[2]) {
+  auto test8 = [&](const SphF2(&S)[8], int k) {
+    v2f q0[4], q1[4];
+    const SphF2(&S0)[4] = reinterpret_cast<const SphF2(&)[4]>(S[0]);
+    const SphF2(&S1)[4] = reinterpret_cast<const SphF2(&)[4]>(S[4]);
+    sph4_primary_filter_pk(S0, d.x, d.y, d.z, q0);
+    sph4_primary_filter_pk(S1, d.x, d.y, d.z, q1);
+    const int m = max_bits8(q1, max_bits8(q0, -1));
+    if (ANY_LANE_RARE(m >= 0)) {
+      const V3<v2f> dv[1] = {d};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        DevSphP E[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) E[i] = rece(k + 4 * j + i);
+        test_sph_primary<v2f, 1, 4>(E, base + k + 4 * j, dv, h);
+      }
+    }
+  };
+  if (n >= 8) {
+    SphF2 A[8], B[8];
+    fetch_batch(recf, 0, A);
+    for (int k = 0; k < n; k += 16) {
+      fetch_batch(recf, recf.landed(A[7].zc, min(k + 8, n - 8)), B);
+      test8(A, k);
+      if (k + 8 >= n) break; // odd number of 8-blocks: B was a clamped refetch, unused
+      fetch_batch(recf, recf.landed(B[7].zc, min(k + 16, n - 8)), A);
+      test8(B, k + 8);
+    }
+  }
+}
+
 // ---- any-hit (main.cpp:314-329), general origin -------------------------------------------
 // Per-pixel state of one occlusion() call.  tb is the bound: > 0 while the ray is still
 // looking, set to 0 once it found its FIRST occluder (or if it never looked), so later
@@ -682,6 +783,153 @@ DEVINL int anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a) 
   return swept;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Shadow-ray FILTER (see "FILTERS" above).  Reference, per (ray O,L ; sphere C,r2), 16 operations:
+//   oc = fl(O - C); b = fl-dot(oc, L); cc = fl(fl-dot(oc, oc) - r2); disc = fl(fl(b b) - cc).
+// With w = O - C (real): |b - w.L| <= 4.01u |w|_1, cc >= |w|^2 - r2 - 6.03u |w|^2 - u r2, so
+// "not disc < 0" implies  T(w) := (w.L)^2 - |w|^2 + r2 >= -(21.03u |w|^2 + u r2 + 2^-149).
+//
+// The filter works relative to a per-scene point g (RenderParams::shadow_center; keeps the
+// magnitudes at the scene's size instead of its distance from the world origin):
+//   per ray    a = fl(O - g), o2 = 2a, nko = fl(-fl-dot(a,a) (1 - 2^-16)), ms = -fl-dot(a, L)
+//   per sphere c = fl(C - g), km = r2 - |c|^2 + 2^-16 (|c|^2 + r2) + 2^-120, rounded up (host, double)
+//   y = fma(cz,o2z, fma(cy,o2y, fma(cx,o2x, nko)))        ~ 2 a.c - |a|^2 (+ ray margin)
+//   x = fma(cz,Lz,  fma(cy,Ly,  fma(cx,Lx,  ms )))        ~ c.L - a.L = -(w'.L),  w' = a - c
+//   q' = fl(fma(x, x, y) + km)                            ~ T(w') + margins        8 operations
+// Error budget, with s2 = |a|^2 + |c|^2:  w' differs from w by the roundings of a and c,
+// |T(w') - T(w)| <= 13.9u s2 and |w|^2 <= 2.0001 s2, so an accepting pair has
+// T(w') >= -(56u s2 + u r2 + 2^-149); the filter's own roundings lose at most 39.4u s2 + 4.01u |a|^2
+// (x: 8.3u (|a|+|c|) absolute -> 33.4u s2 on x^2; y: 3.01u (|a|^2 + s2); the fma: u (3 s2 + |a|^2)).
+// Needed: 99.4u s2 + 4.01u |a|^2 + u r2 + 2^-149.  Provided: >= 251u |a|^2 by nko (2^-16 = 256u, less
+// the 4.02u its own evaluation can lose) and >= 255u (|c|^2 + r2) + 2^-120 by km.  q' is the
+// rounding of (fma + km): sign-exact.  Hence  reference accepts  ==>  q' >= 0.
+// ---------------------------------------------------------------------------------------
+struct PairF { // DevSphPairF as four aligned pairs
+  v2f x, y, z, k;
+};
+struct RayF { // one shadow ray in filter form, as register pairs for op_sel broadcasts
+  v2f o2xy;  // (2ax, 2ay)
+  v2f o2z_n; // (2az, nko)
+  v2f Lxy;   // (Lx, Ly)
+  v2f Lz_s;  // (Lz, ms)
+};
+DEVINL RayF make_ray_filter(f3 o, f3 L, const float (&g)[3]) {
+  const float ax = o.x - g[0], ay = o.y - g[1], az = o.z - g[2];
+  const float n = (ax * ax + ay * ay) + az * az;
+  const float s = (ax * L.x + ay * L.y) + az * L.z;
+  RayF r;
+  r.o2xy = v2f{ax + ax, ay + ay};
+  r.o2z_n = v2f{az + az, n * -0.9999847412109375f}; // -(1 - 2^-16)
+  r.Lxy = v2f{L.x, L.y};
+  r.Lz_s = v2f{L.z, -s};
+  return r;
+}
+
+// 4 pair records (8 spheres) x 1 ray: q[i] = (x_i^2 + y_i) + km_i; 8 independent chains, so no
+// v_pk result is consumed within the next 3 instructions (rule measured in tools/ubench)
+DEVINL void pair4_any_filter_pk(const PairF (&R)[4], const RayF &r, v2f (&q)[4]) {
+  v2f x0, x1, x2, x3;
+  asm("v_pk_fma_f32 %[y0], %[r0x], %[oxy], %[ozn] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1x], %[oxy], %[ozn] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y2], %[r2x], %[oxy], %[ozn] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y3], %[r3x], %[oxy], %[ozn] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0x], %[lxy], %[lzs] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1x], %[lxy], %[lzs] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x2], %[r2x], %[lxy], %[lzs] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x3], %[r3x], %[lxy], %[lzs] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0y], %[oxy], %[y0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1y], %[oxy], %[y1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y2], %[r2y], %[oxy], %[y2] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y3], %[r3y], %[oxy], %[y3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0y], %[lxy], %[x0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1y], %[lxy], %[x1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[x2], %[r2y], %[lxy], %[x2] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[x3], %[r3y], %[lxy], %[x3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0z], %[ozn], %[y0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1z], %[ozn], %[y1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y2], %[r2z], %[ozn], %[y2] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y3], %[r3z], %[ozn], %[y3] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0z], %[lzs], %[x0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1z], %[lzs], %[x1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x2], %[r2z], %[lzs], %[x2] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x3], %[r3z], %[lzs], %[x3] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[x0], %[x0], %[y0]\n\t"
+      "v_pk_fma_f32 %[y1], %[x1], %[x1], %[y1]\n\t"
+      "v_pk_fma_f32 %[y2], %[x2], %[x2], %[y2]\n\t"
+      "v_pk_fma_f32 %[y3], %[x3], %[x3], %[y3]\n\t"
+      "v_pk_add_f32 %[y0], %[y0], %[r0k]\n\t"
+      "v_pk_add_f32 %[y1], %[y1], %[r1k]\n\t"
+      "v_pk_add_f32 %[y2], %[y2], %[r2k]\n\t"
+      "v_pk_add_f32 %[y3], %[y3], %[r3k]\n\t"
+      "s_nop 0"
+      : [y0] "=&v"(q[0]), [y1] "=&v"(q[1]), [y2] "=&v"(q[2]), [y3] "=&v"(q[3]), [x0] "=&v"(x0),
+        [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3)
+      : [oxy] "v"(r.o2xy), [ozn] "v"(r.o2z_n), [lxy] "v"(r.Lxy), [lzs] "v"(r.Lz_s),
+        [r0x] "s"(R[0].x), [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0k] "s"(R[0].k),
+        [r1x] "s"(R[1].x), [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1k] "s"(R[1].k),
+        [r2x] "s"(R[2].x), [r2y] "s"(R[2].y), [r2z] "s"(R[2].z), [r2k] "s"(R[2].k),
+        [r3x] "s"(R[3].x), [r3y] "s"(R[3].y), [r3z] "s"(R[3].z), [r3k] "s"(R[3].k));
+}
+
+// any-hit over pair records through the filter: 4 records (8 spheres) per step, double-buffered
+// scalar fetches; a step in which any lane has q' >= 0 re-reads its EXACT records and runs the
+// reference arithmetic (pair2_any_pk + sph_exact) on them, in index order.  Returns the records
+// this wave swept (wave-uniform).
+constexpr int kFilterExitRecords = 128; // exit check every 256 spheres
+template <typename FetchF, typename FetchE>
+DEVINL int anyhit_sph_pairs_filter(FetchF recf, FetchE rece, int n_rec, int base, f3 o, f3 L,
+                                   const RayF &rf, Any &a) {
+  int swept = 0;
+  const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
+  auto exact4 = [&](int k, int nrec) { // records k .. k+nrec-1 (nrec <= 4), index order
+    for (int j = 0; j < nrec; j += 2) {
+      const int k1 = min(k + j + 1, k + nrec - 1);
+      const PairG R[2] = {rece(k + j), rece(k1)};
+      v2f b[2], q[2];
+      pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (j + i >= nrec) break;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float t2;
+          if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2)) {
+            a.tocc = t2;
+            a.kocc = base + 2 * (k + j + i) + c;
+            a.tb = 0.f;
+          }
+        }
+      }
+    }
+  };
+  auto test4 = [&](const PairF(&R)[4], int k) {
+    v2f q[4];
+    pair4_any_filter_pk(R, rf, q);
+    const int m = max_bits8(q, -1);
+    // a decided / dead lane (tb == 0) may still raise the flag; the exact code accepts nothing for it
+    if (ANY_LANE_RARE(m >= 0)) exact4(k, 4);
+  };
+  for (int k0 = 0; k0 < n_rec; k0 += kFilterExitRecords) {
+    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return swept;
+    const int m = min(kFilterExitRecords, n_rec - k0);
+    swept += m;
+    const int m4 = m & ~3;
+    if (m4) {
+      PairF A[4], B[4];
+      fetch_batch(recf, k0, A);
+      for (int k = 0; k < m4; k += 8) {
+        fetch_batch(recf, recf.landed(A[3].k, k0 + min(k + 4, m4 - 4)), B);
+        test4(A, k0 + k);
+        if (k + 4 >= m4) break;
+        fetch_batch(recf, recf.landed(B[3].k, k0 + min(k + 8, m4 - 4)), A);
+        test4(B, k0 + k + 4);
+      }
+    }
+    if (m4 < m) exact4(k0 + m4, m - m4); // < 4 records left: straight to the reference arithmetic
+  }
+  return swept;
+}
 
 // ---------------------------------------------------------------------------------------
 // re-packing of undecided shadow rays inside a workgroup

@@ -22,7 +22,7 @@ static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNod
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevSphP *sph_p, esc::DevSphPairP *sph2_p,
-                                  hipStream_t stream);
+                                  esc::DevSphF *sph_f, hipStream_t stream);
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
@@ -61,6 +61,9 @@ struct esc_context {
   esc::DevSphP *d_sph_p = nullptr;
   esc::DevSphPair *d_sph2 = nullptr;
   esc::DevSphPairP *d_sph2_p = nullptr;
+  esc::DevSphF *d_sph_f = nullptr;      // filter forms (rt_brute.h "FILTERS")
+  esc::DevSphPairF *d_sph2_f = nullptr;
+  float shadow_center[3] = {0, 0, 0};
   int32_t *d_sph_mat = nullptr;
   esc::DevMat *d_mat = nullptr;
   esc::DevLight *d_lights = nullptr;
@@ -296,8 +299,47 @@ int commit(esc_context *ctx, const Staged &s) {
       sph2[j].cz[h] = real ? s.sph[k].cz : 0.f;
       sph2[j].r2[h] = real ? s.sph[k].r2 : -__builtin_huge_valf(); // cc = +inf: never hit
     }
+  // filter form of the pair table for shadow rays (rt_brute.h, proof next to pair4_any_filter_pk):
+  // centres relative to g = middle of the box of sphere centres, km rounded UP from double
+  float g[3] = {0.f, 0.f, 0.f};
+  if (!s.sph.empty()) {
+    float lo[3] = {s.sph[0].cx, s.sph[0].cy, s.sph[0].cz}, hi[3] = {lo[0], lo[1], lo[2]};
+    for (const auto &q : s.sph) {
+      const float c[3] = {q.cx, q.cy, q.cz};
+      for (int a = 0; a < 3; a++) {
+        lo[a] = std::min(lo[a], c[a]);
+        hi[a] = std::max(hi[a], c[a]);
+      }
+    }
+    for (int a = 0; a < 3; a++) g[a] = (float)(0.5 * ((double)lo[a] + (double)hi[a]));
+  }
+  std::vector<esc::DevSphPairF> sph2f(sph2.size());
+  for (size_t j = 0; j < sph2f.size(); j++)
+    for (int h = 0; h < 2; h++) {
+      const size_t k = 2 * j + h;
+      esc::DevSphPairF &F = sph2f[j];
+      if (k >= s.sph.size()) {
+        F.cx[h] = F.cy[h] = F.cz[h] = 0.f;
+        F.km[h] = -__builtin_huge_valf(); // q' = -inf: never a candidate
+        continue;
+      }
+      const float c[3] = {(float)((double)s.sph[k].cx - g[0]), (float)((double)s.sph[k].cy - g[1]),
+                          (float)((double)s.sph[k].cz - g[2])};
+      const double c2 = (double)c[0] * c[0] + (double)c[1] * c[1] + (double)c[2] * c[2];
+      const double r2 = (double)s.sph[k].r2;
+      const double km = r2 - c2 + 0x1p-16 * (c2 + std::fabs(r2)) + 0x1p-120;
+      float kf = (float)km;
+      if ((double)kf < km) kf = std::nextafterf(kf, __builtin_huge_valf());
+      F.cx[h] = c[0];
+      F.cy[h] = c[1];
+      F.cz[h] = c[2];
+      F.km[h] = kf;
+    }
   HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read old tables
   int rc;
+  if ((rc = upload_vec(ctx->d_sph2_f, sph2f, ctx->stream))) return rc;
+  if ((rc = alloc_dev(ctx->d_sph_f, s.sph.size()))) return rc;
+  std::memcpy(ctx->shadow_center, g, sizeof(g));
   if ((rc = upload_vec(ctx->d_tri, s.tri, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_tri_n, s.tri_n, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph, s.sph, ctx->stream))) return rc;
@@ -490,7 +532,7 @@ void esc_context_destroy(esc_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
-                  ctx->d_sph2,   ctx->d_sph2_p,
+                  ctx->d_sph2,   ctx->d_sph2_p, ctx->d_sph_f, ctx->d_sph2_f,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
@@ -689,6 +731,16 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.sph_p = ctx->d_sph_p;
   p.sph2 = ctx->d_sph2;
   p.sph2_p = ctx->d_sph2_p;
+  p.sph_f = ctx->d_sph_f;
+  p.sph2_f = ctx->d_sph2_f;
+  std::memcpy(p.shadow_center, ctx->shadow_center, 12);
+  {
+    static const bool env_off = [] {
+      const char *e = std::getenv("ESC_FILTER");
+      return e && std::strcmp(e, "0") == 0;
+    }();
+    p.use_filter = (env_off || (opts->flags & ESC_RENDER_EXACT_ONLY)) ? 0 : 1;
+  }
   p.sph_mat = ctx->d_sph_mat;
   p.mat = ctx->d_mat;
   p.lights = ctx->d_lights;
@@ -715,7 +767,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   }
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
-    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_sph_p, ctx->d_sph2_p, ctx->stream);
+    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_sph_p, ctx->d_sph2_p, ctx->d_sph_f,
+                               ctx->stream);
     if (e) {
       set_error(std::string("k_prepare_primary launch: ") + hipGetErrorString((hipError_t)e));
       return ESC_ERR_HIP;

@@ -53,6 +53,26 @@ struct alignas(16) DevSphPairP { // primary form (per frame)
   float ocx[2], ocy[2], ocz[2], cc[2];
 };
 
+// ---------------------------------------------------------------------------------------
+// Conservative FILTER forms of the sphere tables (rt_brute.h "filters").  The hot loops no longer
+// evaluate the reference's discriminant for every (ray, sphere): they evaluate a cheaper FMA
+// expression q' that is >= 0 whenever the reference's own fp32 arithmetic could accept the pair
+// (margins below; proof at the top of rt_brute.h), and only the rare batches with a candidate run
+// the reference arithmetic, on the exact records above.  A filter record is NOT reference data:
+// nothing computed from it reaches the image.
+// ---------------------------------------------------------------------------------------
+// primary rays (per frame): same layout as DevSphP, with ccm = cc - 2^-19 (A^2 + r2) - 2^-120,
+// A = |ocx| + |ocy| + |ocz|
+struct alignas(16) DevSphF {
+  float ocx, ocy, ocz, ccm;
+};
+// shadow rays (per scene): two spheres per record like DevSphPair, centres relative to the scene
+// point `shadow_center` g: c' = fl(c - g), km = r2 - |c'|^2 + 2^-16 (|c'|^2 + r2) + tiny, rounded up.
+// Pad half: c' = 0, km = -inf (q' = -inf: never a candidate).
+struct alignas(16) DevSphPairF {
+  float cx[2], cy[2], cz[2], km[2];
+};
+
 // scene.h:11-18 Material + whether the owning geometry has normals (main.cpp:733)
 struct alignas(16) DevMat {
   float ka[3];
@@ -184,6 +204,10 @@ struct RenderParams {
   const DevSphP *sph_p;
   const DevSphPair *sph2;    // ceil(n_sph / 2) records
   const DevSphPairP *sph2_p; // ceil(n_sph / 2) records
+  const DevSphF *sph_f;      // filter form of sph_p (per frame), n_sph records
+  const DevSphPairF *sph2_f; // filter form of sph2 (per scene), ceil(n_sph / 2) records
+  float shadow_center[3];    // g of DevSphPairF
+  int32_t use_filter;        // 0: every test runs the reference arithmetic (A/B switch, tests)
   const int32_t *sph_mat; // material index of sphere k (already offset by n_geom)
   const DevMat *mat;      // [n_geom + n_sphere_materials]
   const DevLight *lights;

@@ -44,7 +44,8 @@ namespace esc {
 __global__ void __launch_bounds__(256)
 k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, int n_tri,
                   const DevSph *__restrict__ sph, DevSphP *__restrict__ sph_p,
-                  DevSphPairP *__restrict__ sph2_p, int n_sph, float ox, float oy, float oz) {
+                  DevSphPairP *__restrict__ sph2_p, DevSphF *__restrict__ sph_f, int n_sph,
+                  float ox, float oy, float oz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const f3 o = mk(ox, oy, oz);
   if (i < n_tri) {
@@ -70,6 +71,15 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, i
     P.ocz = oc.z;
     P.cc = dot(oc, oc) - S.r2;
     sph_p[i] = P;
+    { // filter form (rt_brute.h "FILTERS"): ccm = cc - 2^-19 (A^2 + r2) - 2^-120
+      const float A = (fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z);
+      DevSphF F;
+      F.ocx = oc.x;
+      F.ocy = oc.y;
+      F.ocz = oc.z;
+      F.ccm = P.cc - ((A * A + fabsf(S.r2)) * 0x1p-19f + 0x1p-120f);
+      sph_f[i] = F;
+    }
     DevSphPairP &Q = sph2_p[i >> 1]; // same values, pair-interleaved (each thread owns a half)
     Q.ocx[i & 1] = P.ocx;
     Q.ocy[i & 1] = P.ocy;
@@ -196,10 +206,14 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   if (STAGE == STAGE_SMEM) {
     closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dv, hit);
     if constexpr (PX == 2) {
-      // multiples of 8 through the hand-scheduled packed body, the tail through the generic one
+      // multiples of 8 through the hand-scheduled packed bodies, the tail through the generic one
       const int n8 = p.n_sph & ~7;
-      closest_sph_primary_pk(SmemFetch<SphP2>{reinterpret_cast<const SphP2 *>(p.sph_p)}, n8,
-                             p.n_tri, dv[0], hit);
+      if (p.use_filter)
+        closest_sph_primary_filter(SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sph_f)},
+                                   SmemFetch<DevSphP>{p.sph_p}, n8, p.n_tri, dv[0], hit);
+      else
+        closest_sph_primary_pk(SmemFetch<SphP2>{reinterpret_cast<const SphP2 *>(p.sph_p)}, n8,
+                               p.n_tri, dv[0], hit);
       closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p + n8}, p.n_sph - n8, p.n_tri + n8, dv,
                                  hit);
     } else if constexpr (PX == 1) {
@@ -420,6 +434,12 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
               const V3<V> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
               n_swept += n_here; // upper bound: exits inside a segment are not subtracted
               anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri + k0}, n_here, k0, sov, sLv, aa);
+            } else if (p.use_filter) {
+              const RayF rf = make_ray_filter(so, sL, p.shadow_center);
+              n_swept += 2 * anyhit_sph_pairs_filter(
+                                 SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sph2_f) + k0},
+                                 SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + k0},
+                                 n_here, p.n_tri + 2 * k0, so, sL, rf, aa[0]);
             } else {
               n_swept += 2 * anyhit_sph_pairs(
                                  SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + k0},
@@ -620,12 +640,12 @@ extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t ran
 // ---------------------------------------------------------------------------------------
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevSphP *sph_p, esc::DevSphPairP *sph2_p,
-                                  hipStream_t stream) {
+                                  esc::DevSphF *sph_f, hipStream_t stream) {
   const int n = p->n_tri > p->n_sph ? p->n_tri : p->n_sph;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
-                     tri_p, p->n_tri, p->sph, sph_p, sph2_p, p->n_sph, p->origin[0], p->origin[1],
-                     p->origin[2]);
+                     tri_p, p->n_tri, p->sph, sph_p, sph2_p, sph_f, p->n_sph, p->origin[0],
+                     p->origin[1], p->origin[2]);
   return (int)hipGetLastError();
 }
 

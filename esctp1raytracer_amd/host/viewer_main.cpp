@@ -139,7 +139,7 @@ int main(int argc, char *argv[]) {
     check(esc_render_frame_host(ctx, &cam, 2, 2, &w, tiny, nullptr), "warm-up");
   } else if (ispc) { // the seam owns its context: a 2x2 call through it does the same
     esc_flat_scene *fs = nullptr;
-    check(esc_flatten_ispc(scene, 1, &fs), "flatten_scene_ispc");
+    check(esc_flatten_ispc(scene, 0, &fs), "flatten_scene_ispc");
     ispc_cam icam;
     esc_new_ispc_cam(&icam, eye, look, vup, vfov, aspect);
     int32_t nt = 0, nl = 0, nlt = 0;
@@ -156,7 +156,11 @@ int main(int argc, char *argv[]) {
   if (ispc) {
     // main.cpp:591-624: flatten inside the timed region, then the exported trace symbol
     esc_flat_scene *fs = nullptr;
-    check(esc_flatten_ispc(scene, /*sort_by_centroid_x=*/1, &fs), "flatten_scene_ispc");
+    // (geometry, face) order, NOT the reference's centroid-x sort (flatten_iscp.cpp:110): the
+    // sort permutes primitive indices, which changes equal-t ties and -- with two or more lights
+    // -- the first occluder occlusion() reports in index order, whose t2 the next light's shadow
+    // ray starts from (quirk S3).  Unsorted, --ispc writes the scalar path's image bit for bit.
+    check(esc_flatten_ispc(scene, /*sort_by_centroid_x=*/0, &fs), "flatten_scene_ispc");
     ispc_cam icam;
     esc_new_ispc_cam(&icam, eye, look, vup, vfov, aspect);
     int32_t nt = 0, nl = 0, nlt = 0;

@@ -142,8 +142,9 @@ typedef struct ispc_cam {
 
 typedef struct esc_flat_scene esc_flat_scene;
 /* flatten_scene_ispc (flatten_iscp.cpp:35-111).  sort_by_centroid_x != 0 reproduces the
- * reference's std::sort at flatten_iscp.cpp:110 (it changes tie order vs the scalar path);
- * 0 keeps (geometry, face) order == the scalar path's order.  Unlike the reference
+ * reference's std::sort at flatten_iscp.cpp:110 (it permutes primitive indices: equal-t ties and,
+ * with >= 2 lights, the first occluder in index order -- quirk S3 -- can change);
+ * 0 keeps (geometry, face) order == the scalar path's order and image.  Unlike the reference
  * (dangling vector, defect I4) the light_faces arrays stay valid until esc_flat_free. */
 int esc_flatten_ispc(const esc_scene *scene, int32_t sort_by_centroid_x, esc_flat_scene **out);
 void esc_flat_free(esc_flat_scene *flat);
@@ -207,8 +208,16 @@ typedef struct {
   int32_t pixels_per_lane; /* 0 = auto; 1, 2 or 4 pixels carried by each work-item (same row,
                               16 columns apart).  Purely a scheduling choice: results are
                               bit-identical for every value. */
-  int32_t reserved;
+  int32_t flags; /* ESC_RENDER_*; 0 = defaults */
 } esc_render_options;
+
+enum {
+  /* Brute force evaluates a cheap conservative FILTER per (ray, sphere) and runs the reference
+   * arithmetic only where the filter cannot rule a hit out (csrc/rt_brute.h "FILTERS"); the image
+   * is the same bit for bit.  This flag (or $ESC_FILTER=0) runs the reference arithmetic for
+   * every pair instead -- the round-1 kernels, kept as the A/B and as a cross-check in tests. */
+  ESC_RENDER_EXACT_ONLY = 1
+};
 
 typedef struct {
   uint64_t primary_rays; /* pixels rendered */

@@ -1,0 +1,135 @@
+"""The conservative sphere FILTERS of the brute-force kernels (csrc/rt_brute.h "FILTERS"), checked
+on the CPU: a numpy mirror of the filter expressions against the reference's own fp32
+arithmetic (restated here operation by operation) on millions of adversarial
+(ray, sphere) pairs that graze the silhouette.
+
+Property (what the kernels rely on):   the reference does not reject at `disc < 0`  ==>  q' >= 0.
+The proof is in rt_brute.h; this is the experiment that would catch a slip in it.  The GPU side
+of the same claim is tests/test_gpu_parity.py::test_filter_equals_exact_only (whole frames, the
+filtered kernels against ESC_RENDER_EXACT_ONLY and the oracle).
+
+fp32 fma is emulated as float32(float64(a) * float64(b) + float64(c)): the product is exact in
+double; the double rounding of the sum can differ from a true fma by one fp32 ulp at most, and
+never in sign -- the margins (32u / 256u against 13.3u / ~100u needed) dwarf it.
+"""
+import numpy as np
+import pytest
+
+f32 = np.float32
+U = 2.0 ** -24
+
+
+def fma(a, b, c):
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+
+
+def ref_dot(ax, ay, az, bx, by, bz):  # vec.h:95-101 order, no fusion
+    return f32(f32(f32(ax * bx) + f32(ay * by)) + f32(az * bz))
+
+
+def unit(v):
+    n = np.sqrt((v.astype(np.float64) ** 2).sum(axis=1, keepdims=True))
+    return (v / n).astype(f32)
+
+
+def grazing_rays(rng, o, c, r, n):
+    """n unit directions from o that pass the sphere (c, r) at (1 + delta) r, |delta| from 1e-7
+    to 1e-2, both signs: half would hit, half would miss, all by a hair."""
+    oc = (c - o).astype(np.float64)
+    dist = np.linalg.norm(oc, axis=1, keepdims=True)
+    w = oc / dist
+    a = rng.normal(size=(n, 3))
+    perp = a - (a * w).sum(axis=1, keepdims=True) * w
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    delta = rng.choice([-1.0, 1.0], size=(n, 1)) * 10.0 ** rng.uniform(-7, -2, size=(n, 1))
+    s = np.clip(r.astype(np.float64)[:, None] * (1.0 + delta) / dist, 0.0, 0.999999)
+    d = w * np.sqrt(1.0 - s * s) + perp * s
+    return unit(d)
+
+
+@pytest.mark.parametrize("scale", [1.0, 30.0, 1000.0])
+def test_primary_filter_never_rejects_a_reference_candidate(scale):
+    """k_prepare_primary's DevSphF + sph4_primary_filter_pk vs the hoisted reference test
+    (b = dot(oc, d); disc = b*b - cc)."""
+    rng = np.random.default_rng(int(scale))
+    n = 1_500_000
+    o = (rng.uniform(-1, 1, (n, 3)) * scale).astype(f32)
+    c = (rng.uniform(-1, 1, (n, 3)) * scale).astype(f32)
+    r = (10.0 ** rng.uniform(-3, 0, n) * scale * 0.2).astype(f32)
+    d = grazing_rays(rng, o, c, r, n)
+    # hoisted per-sphere values exactly as k_prepare_primary computes them
+    ocx, ocy, ocz = f32(o[:, 0] - c[:, 0]), f32(o[:, 1] - c[:, 1]), f32(o[:, 2] - c[:, 2])
+    r2 = f32(r * r)
+    cc = f32(ref_dot(ocx, ocy, ocz, ocx, ocy, ocz) - r2)
+    A = f32(f32(np.abs(ocx) + np.abs(ocy)) + np.abs(ocz))
+    ccm = f32(cc - f32(f32(f32(f32(A * A) + np.abs(r2)) * f32(2.0 ** -19)) + f32(2.0 ** -120)))
+    # reference: not rejected at `disc < 0`
+    b = ref_dot(ocx, ocy, ocz, d[:, 0], d[:, 1], d[:, 2])
+    disc = f32(f32(b * b) - cc)
+    ref_candidate = ~(disc < 0)
+    # filter
+    bf = fma(ocz, d[:, 2], fma(ocy, d[:, 1], f32(ocx * d[:, 0])))
+    qf = fma(bf, bf, -ccm)
+    filt_candidate = qf >= 0
+    assert ref_candidate.sum() > n // 4 and (~ref_candidate).sum() > n // 4
+    missed = ref_candidate & ~filt_candidate
+    assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the filter"
+    # and it is a FILTER: away from the silhouette it rejects (here every ray grazes within 1 %,
+    # so most are passed; a random direction must not be)
+    dr = unit(rng.normal(size=(n, 3)))
+    bf = fma(ocz, dr[:, 2], fma(ocy, dr[:, 1], f32(ocx * dr[:, 0])))
+    assert (fma(bf, bf, -ccm) >= 0).mean() < 0.25
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (30.0, 0.0), (30.0, 500.0), (1000.0, 0.0)])
+def test_shadow_filter_never_rejects_a_reference_candidate(scale, offset):
+    """commit()'s DevSphPairF + make_ray_filter + pair4_any_filter_pk vs the reference's 16-op
+    shadow test (oc = o - c; b = dot(oc, L); cc = dot(oc, oc) - r2; disc = b*b - cc).  `offset`
+    moves the whole scene away from the world origin: the filter works relative to the scene
+    point g, so its margins must not care."""
+    rng = np.random.default_rng(7 + int(scale) + int(offset))
+    n = 1_500_000
+    o = (rng.uniform(-1, 1, (n, 3)) * scale + offset).astype(f32)
+    c = (rng.uniform(-1, 1, (n, 3)) * scale + offset).astype(f32)
+    r = (10.0 ** rng.uniform(-3, 0, n) * scale * 0.2).astype(f32)
+    L = grazing_rays(rng, o, c, r, n)
+    r2 = f32(r * r)
+    # reference
+    ocx, ocy, ocz = f32(o[:, 0] - c[:, 0]), f32(o[:, 1] - c[:, 1]), f32(o[:, 2] - c[:, 2])
+    b = ref_dot(ocx, ocy, ocz, L[:, 0], L[:, 1], L[:, 2])
+    cc = f32(ref_dot(ocx, ocy, ocz, ocx, ocy, ocz) - r2)
+    disc = f32(f32(b * b) - cc)
+    ref_candidate = ~(disc < 0)
+    # host side of the filter (rt_capi.cpp commit()): g, c' = fl(c - g), km rounded up from double
+    g = (0.5 * (c.min(axis=0).astype(np.float64) + c.max(axis=0).astype(np.float64))).astype(f32)
+    cp = (c.astype(np.float64) - g.astype(np.float64)).astype(f32)
+    c2 = (cp.astype(np.float64) ** 2).sum(axis=1)
+    km_d = r2.astype(np.float64) - c2 + 2.0 ** -16 * (c2 + np.abs(r2.astype(np.float64))) + 2.0 ** -120
+    km = km_d.astype(f32)
+    low = km.astype(np.float64) < km_d
+    km[low] = np.nextafter(km[low], f32(np.inf))
+    # device side (make_ray_filter, un-fused) ...
+    ax, ay, az = f32(o[:, 0] - g[0]), f32(o[:, 1] - g[1]), f32(o[:, 2] - g[2])
+    nn = ref_dot(ax, ay, az, ax, ay, az)
+    ss = ref_dot(ax, ay, az, L[:, 0], L[:, 1], L[:, 2])
+    nko = f32(nn * f32(-(1.0 - 2.0 ** -16)))
+    ms = f32(-ss)
+    # ... and pair4_any_filter_pk
+    y = fma(cp[:, 2], f32(az + az), fma(cp[:, 1], f32(ay + ay), fma(cp[:, 0], f32(ax + ax), nko)))
+    x = fma(cp[:, 2], L[:, 2], fma(cp[:, 1], L[:, 1], fma(cp[:, 0], L[:, 0], ms)))
+    q = f32(fma(x, x, y) + km)
+    filt_candidate = q >= 0
+    assert ref_candidate.sum() > n // 4 and (~ref_candidate).sum() > n // 4
+    missed = ref_candidate & ~filt_candidate
+    assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the filter"
+    Lr = unit(rng.normal(size=(n, 3)))
+    ssr = ref_dot(ax, ay, az, Lr[:, 0], Lr[:, 1], Lr[:, 2])
+    xr = fma(cp[:, 2], Lr[:, 2], fma(cp[:, 1], Lr[:, 1], fma(cp[:, 0], Lr[:, 0], f32(-ssr))))
+    assert (f32(fma(xr, xr, y) + km) >= 0).mean() < 0.25
+
+
+def test_filter_margins_match_the_documented_budget():
+    """the constants the proof in rt_brute.h quotes: provided margins exceed the needed ones"""
+    assert 32 * U == 2.0 ** -19 and 256 * U == 2.0 ** -16
+    assert 32 > 13.3 + 1 + 5 * 32 * U          # primary: 13.3u + rounding of ccm + of A2f
+    assert 251 > 99.4 + 4.01 and 255 > 99.4     # shadow: ray side (nko), sphere side (km)

@@ -383,7 +383,7 @@ def test_bench_two_ranks_gloo_on_one_gpu(tmp_path, gather):
 
 def test_trace_drop_in(esc, renderer):
     """The ispc::trace symbol on FlatScene arrays == the scene path, with and without the
-    reference's centroid-x sort (the sort only permutes equal-t ties)."""
+    reference's centroid-x sort (in this one-light scene the sort only permutes equal-t ties)."""
     d = ol.load_dump("CornellBox-Original")
     sc = ol.scene_to_product(d)
     W, H = 128, 96
