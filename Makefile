@@ -14,7 +14,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
             -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize \
             -Iinclude -I$(PKG)/host -I$(PKG)/csrc -Wall -Wno-unused-function
 
-LIB_SRC  := $(PKG)/csrc/rt_kernels.hip $(PKG)/csrc/rt_capi.cpp \
+LIB_SRC  := $(PKG)/csrc/rt_kernels.hip $(PKG)/csrc/rt_capi.cpp $(PKG)/csrc/rt_multi.cpp \
             $(PKG)/host/host_core.cpp $(PKG)/host/obj_loader.cpp $(PKG)/host/synth.cpp \
             $(PKG)/host/accel_build.cpp
 LIB_HDR  := include/esctp1_rt.h $(PKG)/csrc/rt_device.h $(PKG)/csrc/rt_math.h $(PKG)/csrc/rt_brute.h $(PKG)/csrc/rt_accel.h $(PKG)/host/scene.h $(PKG)/host/accel_build.h
@@ -25,7 +25,7 @@ lib: $(LIB)
 
 $(LIB): $(LIB_SRC) $(LIB_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_SRC)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_SRC) -ldl
 
 viewer: $(VIEWER)
 

@@ -13,11 +13,12 @@ import numpy as np
 
 from . import _capi
 from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_BVH, ESC_STAGE_LDS,
-                    ESC_RENDER_EXACT_ONLY, ESC_STAGE_SMEM, EscError, check)
+                    ESC_RENDER_EXACT_ONLY, ESC_RENDER_TIME_KERNELS, ESC_STAGE_SMEM, EscError,
+                    check)
 
-__all__ = ["Scene", "Camera", "Renderer", "FlatScene", "render_multi", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
+__all__ = ["Scene", "Camera", "Renderer", "FlatScene", "MultiRenderer", "render_multi", "render_multi_rccl", "rccl_available", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
            "EscError", "ESC_FACE_FIXED", "ESC_FACE_HASH", "ESC_STAGE_AUTO", "ESC_STAGE_SMEM",
-           "ESC_STAGE_LDS", "ESC_STAGE_BVH", "ESC_RENDER_EXACT_ONLY", "version"]
+           "ESC_STAGE_LDS", "ESC_STAGE_BVH", "ESC_RENDER_EXACT_ONLY", "ESC_RENDER_TIME_KERNELS", "version"]
 
 
 def _f32(a, shape=None):
@@ -342,6 +343,12 @@ class Renderer:
                                            "sph_nodes", "sph_blocks", "sph_depth", "sph_root",
                                            "build_ms", "builds")}
 
+    def last_kernel_ms(self):
+        """(k_primary ms, k_shade ms) of the last frame rendered with ESC_RENDER_TIME_KERNELS."""
+        ms = np.zeros(2, np.float32)
+        check(self._lib.esc_last_kernel_ms(self._h, _fp(ms)))
+        return float(ms[0]), float(ms[1])
+
     def reset_counters(self):
         check(self._lib.esc_reset_counters(self._h))
 
@@ -370,6 +377,68 @@ def render_multi(scene, camera, W, H, n_devices, *, want_u8=False, shadows=True,
                                      _fp(img),
                                      u8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_u8 else None,
                                      _fp(ms)))
+    return img, u8, ms
+
+
+def rccl_available():
+    """True when librccl.so could be bound at run time (esc_rccl_available)."""
+    return bool(_capi.load().esc_rccl_available())
+
+
+class MultiRenderer:
+    """esc_multi: one process, n devices, 8-row strips dealt round-robin, the framebuffer gathered
+    to the first device over RCCL (use_rccl=True) or by peer copies, then assembled there."""
+
+    def __init__(self, n_devices, device_ids=None, use_rccl=True):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        ids = None
+        if device_ids is not None:
+            ids = (C.c_int32 * n_devices)(*[int(d) for d in device_ids])
+        check(self._lib.esc_multi_create(int(n_devices), ids, 1 if use_rccl else 0,
+                                         C.byref(self._h)))
+        self.n_devices = int(n_devices)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.esc_multi_destroy(h)
+
+    def __del__(self):
+        self.close()
+
+    def upload(self, scene):
+        check(self._lib.esc_multi_upload_scene(self._h, scene._h))
+
+    def render(self, camera, W, H, *, gather_u8=False, shadows=True, face_mode=ESC_FACE_FIXED,
+               fixed_face=0, seed=0, stage=ESC_STAGE_AUTO, flags=0):
+        """-> ((H, W, 3) fp32 or uint8 frame, per-device render ms, device address of the frame)"""
+        o = _options(shadows, face_mode, fixed_face, seed, stage, 0, flags)
+        ms = np.zeros(self.n_devices, np.float32)
+        dptr = C.c_void_p()
+        if gather_u8:
+            out = np.zeros((H, W, 3), np.uint8)
+            check(self._lib.esc_multi_render(self._h, C.byref(camera.c), W, H, C.byref(o), 1, None,
+                                             out.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                             C.byref(dptr), _fp(ms)))
+        else:
+            out = np.zeros((H, W, 3), np.float32)
+            check(self._lib.esc_multi_render(self._h, C.byref(camera.c), W, H, C.byref(o), 0,
+                                             _fp(out), None, C.byref(dptr), _fp(ms)))
+        return out, ms, dptr.value
+
+
+def render_multi_rccl(scene, camera, W, H, n_devices, *, want_u8=False, shadows=True,
+                      face_mode=ESC_FACE_FIXED, fixed_face=0, seed=0, stage=ESC_STAGE_AUTO):
+    """esc_render_frame_multi_rccl: the one-call form (communicator set up and torn down inside)."""
+    lib = _capi.load()
+    img = np.zeros((H, W, 3), np.float32)
+    u8 = np.zeros((H, W, 3), np.uint8) if want_u8 else None
+    ms = np.zeros(n_devices, np.float32)
+    o = _options(shadows, face_mode, fixed_face, seed, stage)
+    check(lib.esc_render_frame_multi_rccl(
+        scene._h, C.byref(camera.c), W, H, C.byref(o), n_devices, _fp(img),
+        u8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_u8 else None, _fp(ms)))
     return img, u8, ms
 
 

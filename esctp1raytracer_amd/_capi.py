@@ -18,6 +18,7 @@ ESC_ERR_IO = -3
 ESC_ERR_PARSE = -4
 ESC_ERR_NOMEM = -5
 ESC_ERR_NO_DEVICE = -6
+ESC_ERR_RCCL = -7
 
 ESC_FACE_FIXED = 0
 ESC_FACE_HASH = 1
@@ -27,6 +28,7 @@ ESC_STAGE_LDS = 2
 ESC_STAGE_BVH = 3
 ESC_MATERIAL_FLOATS = 13
 ESC_RENDER_EXACT_ONLY = 1
+ESC_RENDER_TIME_KERNELS = 2
 
 
 class EscError(RuntimeError):
@@ -141,12 +143,23 @@ SIGNATURES = {
     "esc_scene_build_accel": (C.c_int, [_P, _F, C.c_int32, C.POINTER(esc_accel_info),
                                         C.POINTER(esc_bvh_node), C.c_int64, _I32, C.c_int64, _F,
                                         C.c_int64]),
+    "esc_last_kernel_ms": (C.c_int, [_P, _F]),
     "esc_reset_counters": (C.c_int, [_P]),
     "esc_read_counters": (C.c_int, [_P, C.POINTER(esc_counters)]),
     "esc_render_frame_host": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32,
                                         C.POINTER(esc_render_options), _F, _U8]),
     "esc_render_frame_multi": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32,
                                          C.POINTER(esc_render_options), C.c_int32, _F, _U8, _F]),
+    "esc_rccl_available": (C.c_int, []),
+    "esc_multi_create": (C.c_int, [C.c_int32, _I32, C.c_int32, C.POINTER(_P)]),
+    "esc_multi_destroy": (None, [_P]),
+    "esc_multi_upload_scene": (C.c_int, [_P, _P]),
+    "esc_multi_render": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32,
+                                   C.POINTER(esc_render_options), C.c_int32, _F, _U8,
+                                   C.POINTER(_P), _F]),
+    "esc_render_frame_multi_rccl": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32,
+                                              C.POINTER(esc_render_options), C.c_int32, _F, _U8,
+                                              _F]),
     "esc_write_ppm": (C.c_int, [C.c_char_p, _F, C.c_int32, C.c_int32]),
     "esc_write_ppm_u8": (C.c_int, [C.c_char_p, _U8, C.c_int32, C.c_int32]),
     "esc_quantise": (None, [_F, C.c_int64, _U8]),

@@ -33,7 +33,7 @@ extern "C" int esc_launch_bin_light(const esc::LightBins *g, const float *light_
                                     const esc::PrimBoxDev *sph_boxes, int n_sph,
                                     hipStream_t stream);
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px,
-                                 hipStream_t stream);
+                                 hipStream_t stream, hipEvent_t between);
 extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
                                    int n_ranks, int H, int strip_rows, size_t row_bytes,
                                    hipStream_t stream);
@@ -74,7 +74,7 @@ struct esc_context {
   bool have_scene = false;
   bool prepared = false;
   float prepared_origin[3] = {0, 0, 0};
-  esc::HitRec *d_hits = nullptr; // k_primary -> k_shade hand-over
+  int32_t *d_hits = nullptr; // k_primary -> k_shade hand-over: 3 planes (idx, t, v) of hits_cap dwords
   size_t hits_cap = 0;
   // ESC_STAGE_BVH: host copy of the tables the builder reads, the tree in HBM
   std::vector<esc::DevTri> h_tri;
@@ -97,6 +97,9 @@ struct esc_context {
   bool accel_valid = false;
   esc::OriginBounds accel_ob{};
   esc_accel_info accel_info{};
+  // ESC_RENDER_TIME_KERNELS: events around / between the two frame kernels of the last frame
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool ev_valid = false;
   // scratch framebuffers for esc_render_frame_host
   float *d_img = nullptr;
   uint8_t *d_u8 = nullptr;
@@ -543,6 +546,8 @@ void esc_context_destroy(esc_context *ctx) {
                   ctx->lbins.sph_ids};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  for (hipEvent_t ev : ctx->ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -760,10 +765,12 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       if (ctx->d_hits) HIP_TRY(hipFree(ctx->d_hits));
       ctx->d_hits = nullptr;
       ctx->hits_cap = 0;
-      HIP_TRY(hipMalloc((void **)&ctx->d_hits, need * sizeof(esc::HitRec)));
+      HIP_TRY(hipMalloc((void **)&ctx->d_hits, need * 3 * sizeof(int32_t)));
       ctx->hits_cap = need;
     }
-    p.hits = ctx->d_hits;
+    p.hits.idx = ctx->d_hits;
+    p.hits.t = reinterpret_cast<float *>(ctx->d_hits + ctx->hits_cap);
+    p.hits.v = reinterpret_cast<float *>(ctx->d_hits + 2 * ctx->hits_cap);
   }
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
@@ -835,7 +842,18 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     stage = 3;
     px = 1; // a wave walks the tree with its 64 rays
   }
-  int e = esc_launch_render(&p, stage, px, ctx->stream);
+  const bool timed = (opts->flags & ESC_RENDER_TIME_KERNELS) != 0;
+  ctx->ev_valid = false;
+  if (timed) {
+    for (auto &ev : ctx->ev)
+      if (!ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  }
+  int e = esc_launch_render(&p, stage, px, ctx->stream, timed ? ctx->ev[1] : nullptr);
+  if (timed && !e) {
+    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    ctx->ev_valid = true;
+  }
   if (e) {
     set_error(std::string("frame kernel launch (k_primary / k_shade): ") + hipGetErrorString((hipError_t)e));
     return ESC_ERR_HIP;
@@ -910,6 +928,22 @@ int esc_assemble_strips(esc_context *ctx, const void *d_gathered, int32_t n_rank
     set_error(std::string("k_assemble_strips launch: ") + hipGetErrorString((hipError_t)e));
     return ESC_ERR_HIP;
   }
+  return ESC_OK;
+}
+
+int esc_last_kernel_ms(esc_context *ctx, float ms[2]) {
+  if (!ctx || !ms) {
+    set_error("esc_last_kernel_ms: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (!ctx->ev_valid) {
+    set_error("esc_last_kernel_ms: the last frame was not rendered with ESC_RENDER_TIME_KERNELS");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&ms[1], ctx->ev[1], ctx->ev[2]));
   return ESC_OK;
 }
 

@@ -99,12 +99,19 @@ struct DevLight {
   int32_t n_faces;
 };
 
-// hand-over between k_primary and k_shade: closest hit of one pixel (main.cpp:715-722 state)
-struct alignas(16) HitRec {
-  float t;     // FLT_MAX when nothing was hit
-  float v;     // quirk S1: only v survives
-  int32_t idx; // -1 none; [0,n_tri) triangle; n_tri + k sphere k
-  int32_t pad;
+// hand-over between k_primary and k_shade: the closest hit of every pixel of the band
+// (main.cpp:715-722 state) as three planes of n_pixels dwords each, so every store / load is a
+// run of consecutive dwords:
+//   idx  -1 none; [0,n_tri) triangle; n_tri + k sphere k          written for every pixel
+//   t    the closest t                                            written for hit pixels only
+//   v    quirk S1: only v survives (main.cpp:307,310)             written for hit pixels, and only
+//                                                                 when some geometry has normals
+// (a 16-byte record per pixel, sky included, cost 2 x 133 MB of HBM traffic per 4K frame; the
+// planes cost 2 x (33 + 0.68 x 33) MB on c4)
+struct HitPlanes {
+  int32_t *idx;
+  float *t;
+  float *v; // only touched when RenderParams::tri_n != nullptr
 };
 
 // ---------------------------------------------------------------------------------------
@@ -218,7 +225,7 @@ struct RenderParams {
   uint8_t *out_u8;  // band-local, may be null
   // kCounterSets replicas of {primary, hit, shadow rays, any-hit tests, 4 spare}, 64 B each
   unsigned long long *counters;
-  HitRec *hits;                 // band-local, n_local_rows * W records (scratch owned by the context)
+  HitPlanes hits;               // band-local, n_local_rows * W pixels (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only
   BinGrid bins;                 // ESC_STAGE_BVH only; hdr == nullptr: no bins, walk the tree
   LightBins lbins;              // ESC_STAGE_BVH only; n_points == 0: none

@@ -243,16 +243,17 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     }
   }
 
-  // ---- hand-over: t, v, idx per pixel (band-local pixel order), 16-byte stores
+  // ---- hand-over: idx for every pixel, t (and v when normals exist) for hit pixels; plane
+  // stores, band-local pixel order
 #pragma unroll
   for (int q = 0; q < PX; ++q)
     if (row_ok && w[q] < p.W) {
-      HitRec r;
-      r.t = hit[q].t;
-      r.v = hit[q].v;
-      r.idx = hit[q].idx;
-      r.pad = 0;
-      p.hits[(size_t)lr * p.W + w[q]] = r;
+      const size_t px = (size_t)lr * p.W + w[q];
+      p.hits.idx[px] = hit[q].idx;
+      if (hit[q].idx >= 0) {
+        p.hits.t[px] = hit[q].t;
+        if (p.tri_n) p.hits.v[px] = hit[q].v;
+      }
     }
 }
 
@@ -276,11 +277,13 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
   const bool inside = (lr < rows) && (h < p.H) && (w < p.W);
 
   const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
-  HitRec hr;
+  struct {
+    float t, v;
+    int32_t idx;
+  } hr;
   hr.t = FLT_MAX;
   hr.v = 0.f;
   hr.idx = -1;
-  hr.pad = 0;
   // ESC_STAGE_BVH is ONE kernel: the closest hit is found right here (screen bin of this tile,
   // else the tree walk) instead of being handed over through HBM by k_primary -- its search
   // holds few registers, so nothing spills, and the primary direction is computed once and kept
@@ -300,7 +303,14 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
     hr.v = s.v;
     hr.idx = (int32_t)s.key; // kNoKey -> -1
   } else {
-    if (inside) hr = p.hits[(size_t)lr * p.W + w];
+    if (inside) {
+      const size_t px = (size_t)lr * p.W + w;
+      hr.idx = p.hits.idx[px];
+      if (hr.idx >= 0) {
+        hr.t = p.hits.t[px];
+        if (p.tri_n) hr.v = p.hits.v[px];
+      }
+    }
   }
   const bool has_hit = inside && (hr.idx >= 0);
 
@@ -690,7 +700,8 @@ static void launch_primary(const esc::RenderParams *p, hipStream_t stream) {
 
 // stage: 1 SMEM, 2 LDS, 3 BVH (px ignored).  px: pixels per work-item of the primary pass (1, 2 or 4); the shade
 // pass always carries one pixel per work-item.
-extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, hipStream_t stream) {
+extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, hipStream_t stream,
+                                 hipEvent_t between) {
   if (p->n_local_rows <= 0 || p->W <= 0) return 0;
   using esc::v2f;
   const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
@@ -701,11 +712,13 @@ extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, 
     if (px == 1) launch_primary<esc::STAGE_LDS, float, 1>(p, stream);
     else if (px == 2) launch_primary<esc::STAGE_LDS, v2f, 1>(p, stream);
     else launch_primary<esc::STAGE_LDS, v2f, 2>(p, stream);
+    if (between) (void)hipEventRecord(between, stream);
     hipLaunchKernelGGL((esc::k_shade<esc::STAGE_LDS>), dim3(shade_grid), dim3(256), 0, stream, *p);
   } else {
     if (px == 1) launch_primary<esc::STAGE_SMEM, float, 1>(p, stream);
     else if (px == 2) launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream);
     else launch_primary<esc::STAGE_SMEM, v2f, 2>(p, stream);
+    if (between) (void)hipEventRecord(between, stream);
     hipLaunchKernelGGL((esc::k_shade<esc::STAGE_SMEM>), dim3(shade_grid), dim3(256), 0, stream, *p);
   }
   return (int)hipGetLastError();

@@ -14,7 +14,9 @@
 //   -w W,H        window size.  NOTE: in the reference this flag writes into `look`
 //                 (main.cpp:515-529) and the window stays 1024x768; here
 //                 it does what its help text says.
-//   --gpus N      row bands over N devices (bands share devices if fewer are present)
+//   --gpus N      8-row strips over N devices from this one process: gathered over RCCL when every
+//                 band has its own GPU, else bands share devices and strips go straight to the host
+//   --no-rccl     keep --gpus on the host-copy path
 //   --scene c2|c3|c4|c5[:n]   synthetic BASELINE.json workload instead of -m
 //   --shadows 0|1  --seed S  --face K   light-face choice: hashed (default) or fixed K
 //   --dump-f32 path           raw fp32 RGB framebuffer, (h*W+w)*3 order, h = 0 bottom
@@ -55,7 +57,7 @@ void parse_floats(const char *flag, char *arg, float *out, int n, const char *er
 
 int main(int argc, char *argv[]) {
   std::string modelname, outputname, dumpname, synthetic;
-  bool threaded = false, flat = false, ispc = false;
+  bool threaded = false, flat = false, ispc = false, no_rccl = false;
   int debug = 1; // INFO, debug.h:3
   float eye[3] = {0, 1, 3}, look[3] = {0, 1, 0}; // main.cpp:426
   int W = 1024, H = 768;                         // main.cpp:427
@@ -84,6 +86,7 @@ int main(int argc, char *argv[]) {
       continue;
     }
     if (a == "--gpus") { if (!next) die("--gpus needs N"); gpus = std::atoi(next); arg++; continue; }
+    if (a == "--no-rccl") { no_rccl = true; continue; }
     if (a == "--scene") { if (!next) die("--scene needs a config"); synthetic = next; arg++; continue; }
     if (a == "--shadows") { if (!next) die("--shadows needs 0|1"); shadows = std::atoi(next); arg++; continue; }
     if (a == "--seed") { if (!next) die("--seed needs S"); seed = std::strtoull(next, nullptr, 0); arg++; continue; }
@@ -175,9 +178,19 @@ int main(int argc, char *argv[]) {
   } else if (ctx) {
     check(esc_render_frame_host(ctx, &cam, W, H, &opts, image.data(), nullptr), "render");
   } else {
+    // N devices from this one process.  With a GPU per band the strips are gathered to device 0
+    // over RCCL (esc_render_frame_multi_rccl); more bands than GPUs (or no RCCL on this host, or
+    // --no-rccl) fall back to the band-sharing path that copies strips straight to the host.
     std::vector<float> ms((size_t)gpus, 0.f);
-    check(esc_render_frame_multi(scene, &cam, W, H, &opts, gpus, image.data(), nullptr, ms.data()),
-          "render");
+    int rc = ESC_ERR_RCCL;
+    if (!no_rccl && esc_rccl_available())
+      rc = esc_render_frame_multi_rccl(scene, &cam, W, H, &opts, gpus, image.data(), nullptr,
+                                       ms.data());
+    if (rc != ESC_OK) {
+      if (debug >= 2) std::cerr << " RCCL path not used: " << esc_last_error() << std::endl;
+      check(esc_render_frame_multi(scene, &cam, W, H, &opts, gpus, image.data(), nullptr, ms.data()),
+            "render");
+    }
     if (debug >= 2)
       for (int i = 0; i < gpus; i++) std::cerr << " band " << i << " kernel ms: " << ms[i] << std::endl;
   }

@@ -33,7 +33,9 @@ enum {
   ESC_ERR_IO = -3,      /* file could not be opened / written */
   ESC_ERR_PARSE = -4,   /* OBJ/MTL rejected (mirrors sceneloader.cpp:27-30,67-70 throws) */
   ESC_ERR_NOMEM = -5,
-  ESC_ERR_NO_DEVICE = -6 /* no usable gfx950 device: the product has NO CPU fallback */
+  ESC_ERR_NO_DEVICE = -6, /* no usable gfx950 device: the product has NO CPU fallback */
+  ESC_ERR_RCCL = -7       /* RCCL missing or an ncclResult_t != ncclSuccess (message carries
+                             ncclGetErrorString) */
 };
 
 const char *esc_last_error(void);
@@ -216,7 +218,11 @@ enum {
    * arithmetic only where the filter cannot rule a hit out (csrc/rt_brute.h "FILTERS"); the image
    * is the same bit for bit.  This flag (or $ESC_FILTER=0) runs the reference arithmetic for
    * every pair instead -- the round-1 kernels, kept as the A/B and as a cross-check in tests. */
-  ESC_RENDER_EXACT_ONLY = 1
+  ESC_RENDER_EXACT_ONLY = 1,
+  /* Record HIP events on the context's stream around and between the frame's two kernels
+   * (k_primary, k_shade); esc_last_kernel_ms reads them.  Brute-force stages only: under
+   * ESC_STAGE_BVH the frame is one kernel and ms[0] is 0. */
+  ESC_RENDER_TIME_KERNELS = 2
 };
 
 typedef struct {
@@ -312,6 +318,9 @@ int esc_scene_build_accel(const esc_scene *scene, const float origin[3], int32_t
                           int32_t *order, int64_t order_cap, float *prim_boxes,
                           int64_t prim_boxes_cap);
 
+/* ms[0] = k_primary, ms[1] = k_shade of the last frame rendered with ESC_RENDER_TIME_KERNELS
+ * (waits for that frame).  This is how bench.py prices each kernel against its own roof. */
+int esc_last_kernel_ms(esc_context *ctx, float ms[2]);
 int esc_reset_counters(esc_context *ctx);
 int esc_read_counters(esc_context *ctx, esc_counters *out);
 
@@ -326,6 +335,35 @@ int esc_render_frame_host(esc_context *ctx, const esc_camera *cam, int32_t W, in
 int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_t W, int32_t H,
                            const esc_render_options *opts, int32_t n_devices, float *image,
                            uint8_t *rgb8, float *ms_per_device /* [n_devices] or NULL */);
+
+/* ---- native multi-GPU with an RCCL gather ------------------------
+ * What a C++ host at the reference's call site (main.cpp:619-624, rows are independent:
+ * main.cpp:628-636) uses to reach all GPUs of a node from ONE process: one context per device,
+ * 8-row strips dealt round-robin (the esc_render_strips partition), every device renders its
+ * strips, and the ONE exchange step -- the framebuffer gather to the first device -- runs over
+ * RCCL: grouped ncclSend / ncclRecv, direct peer -> root over xGMI, fp32 RGB (12 B/pixel, the
+ * `trace` seam's return_image) or the PPM-quantised bytes (3 B/pixel, main.cpp:676-682).  Then
+ * esc_assemble_strips lays the frame out on the first device.  RCCL is bound at run time
+ * (dlopen of librccl.so; $ESC_RCCL_LIB overrides), so the library itself does not link it.
+ *   use_rccl = 0 replaces the exchange by hipMemcpyPeerAsync (same layout; for hosts without RCCL).
+ *   n_devices must not exceed the device count (one communicator rank per device). */
+typedef struct esc_multi esc_multi;
+int esc_rccl_available(void); /* 1 / 0 (esc_last_error says why not) */
+int esc_multi_create(int32_t n_devices, const int32_t *device_ids /* NULL = 0..n-1 */,
+                     int32_t use_rccl, esc_multi **out);
+void esc_multi_destroy(esc_multi *m);
+int esc_multi_upload_scene(esc_multi *m, const esc_scene *scene); /* replicated on every device */
+/* One frame, synchronous.  gather_u8 = 0: fp32 RGB is gathered (`image` may be set, rgb8 must be
+ * NULL); 1: the quantised bytes (`rgb8` may be set, image must be NULL).  Host pointers may be
+ * NULL when only the device-resident frame is wanted: *d_frame (if non-NULL) receives the
+ * assembled frame's address on the first device, valid until the next call on `m`. */
+int esc_multi_render(esc_multi *m, const esc_camera *cam, int32_t W, int32_t H,
+                     const esc_render_options *opts, int32_t gather_u8, float *image,
+                     uint8_t *rgb8, void **d_frame, float *ms_per_device /* [n] or NULL */);
+/* create + upload + render + destroy in one call (the shape of esc_render_frame_multi) */
+int esc_render_frame_multi_rccl(const esc_scene *scene, const esc_camera *cam, int32_t W, int32_t H,
+                                const esc_render_options *opts, int32_t n_devices, float *image,
+                                uint8_t *rgb8, float *ms_per_device /* [n_devices] or NULL */);
 
 /* ------------------------------------------------------------------------------------
  * PPM writer == main.cpp:658-689: "P3\nW H\n255\n", rows top-down, clamp >1, int(c*255)

@@ -208,6 +208,89 @@ def test_sphere_scenes_bit_exact(esc, renderer, config, n, shadows, stage, px):
     assert 0 < rc["hit_pixels"] < W * H
 
 
+@pytest.mark.parametrize("config,W,H", [("c3", 3840, 2160), ("c4", 3840, 2160)])
+def test_filter_equals_exact_only_full_size(esc, renderer, config, W, H):
+    """The brute-force kernels run a conservative FMA filter per (ray, sphere) and the reference
+    arithmetic only where the filter cannot rule a hit out (csrc/rt_brute.h "FILTERS").  Whole
+    BASELINE-size frames: filtered == ESC_RENDER_EXACT_ONLY (the reference arithmetic for every
+    pair) in every fp32 value, every quantised byte and every counter."""
+    import torch
+    sc = esc.Scene.synthetic(config)
+    eye, look = esc.synthetic_view()
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    out = []
+    for flags in (0, esc.ESC_RENDER_EXACT_ONLY):
+        f32 = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda:0")
+        u8 = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda:0")
+        renderer.reset_counters()
+        renderer.render_rows(cam, W, H, 0, H, out_f32=f32, out_u8=u8, flags=flags)
+        cnt = renderer.counters()
+        cnt.pop("anyhit_lane_tests")
+        out.append((f32, u8, cnt))
+    assert int((out[0][0].view(torch.int32) != out[1][0].view(torch.int32)).sum().item()) == 0
+    assert bool((out[0][1] == out[1][1]).all().item())
+    assert out[0][2] == out[1][2]
+    assert float(out[0][0].sum().item()) > 0
+
+
+@pytest.mark.parametrize("case", ["far from the world origin", "tiny and huge radii",
+                                  "camera inside a sphere", "sphere centred on the camera",
+                                  "rays grazing silhouettes", "1e4 scale"])
+def test_filter_adversarial_scenes_vs_oracle(esc, renderer, case):
+    """Scenes chosen against the filters' margins: coordinates much larger than the radii (the
+    margins scale with squared distances), radii spanning 1e-3..1e2, origins inside spheres
+    (cc < 0), grazing rays.  Filtered frame == oracle, bit for bit, with 1 and 2 lights."""
+    rng = np.random.default_rng(len(case) * 7 + ord(case[0]))
+    n = 160
+    off = np.zeros(3)
+    scale = 1.0
+    eye, look = np.array([0.0, 1.0, 6.0]), np.array([0.0, 1.0, 0.0])
+    c = np.concatenate([rng.uniform(-3, 3, (n, 1)), rng.uniform(0.2, 3.5, (n, 1)),
+                        rng.uniform(-4, 2, (n, 1))], axis=1)
+    r = rng.uniform(0.05, 0.4, n)
+    if case == "far from the world origin":
+        off = np.array([700.0, -300.0, 1500.0])
+    elif case == "tiny and huge radii":
+        r = 10.0 ** rng.uniform(-3, 0, n)
+        c[0], r[0] = (0.0, -100.0, -3.0), 100.0  # a planet under everything
+    elif case == "camera inside a sphere":
+        c[0], r[0] = eye + (0.1, 0.05, -0.2), 1.5
+        c[1], r[1] = eye, 40.0                     # and everything inside a big shell
+    elif case == "sphere centred on the camera":
+        c[0], r[0] = eye, 0.25
+    elif case == "rays grazing silhouettes":
+        # rows of equal spheres touching each other: every gap is a tangent configuration
+        k = np.arange(n)
+        c = np.stack([(k % 20) * 0.3 - 2.85, (k // 20) * 0.3 + 0.3, np.full(n, -1.0)], axis=1)
+        r = np.full(n, 0.15)
+    elif case == "1e4 scale":
+        scale = 1.0e4
+    c = (c + off) * scale
+    r = r * scale
+    eye, look = (eye + off) * scale, (look + off) * scale
+    fl = (np.array([[-6, 0, 4], [6, 0, 4], [6, 0, -8], [-6, 0, -8]], float) + off) * scale
+    l1 = (np.array([[-0.3, 7, -1], [0.3, 7, -1], [0, 7, -1.6]], float) + off) * scale
+    l2 = (np.array([[4, 5, 2], [4.4, 5, 2], [4, 5.4, 2.2]], float) + off) * scale
+    for lights in ([l1], [l1, l2]):
+        geoms = [{"vertex": fl[[0, 1, 2, 0, 2, 3]].astype(np.float32),
+                  "face_index": np.arange(6).reshape(2, 3), "material": ol.WHITE}]
+        for lt in lights:
+            geoms.append({"vertex": lt.astype(np.float32), "face_index": np.array([[0, 1, 2]]),
+                          "material": ol.LIGHT_A})
+        sph = np.concatenate([c, r[:, None]], axis=1).astype(np.float32)
+        mats = np.stack([ol.material13(ka=m, kd=m) for m in rng.uniform(0.2, 0.9, (n, 3))])
+        d = ol.scene_dict(geoms, sph, mats)
+        W, H = 224, 128
+        for px in (1, 2):
+            gpu, u8, ref = render_both(esc, renderer, d, tuple(eye), tuple(look), W, H, px=px)
+            assert_bit_equal(gpu, ref, f"filter/{case}/{len(lights)} lights/px{px}")
+        exact = renderer.render(esc.Camera.for_image(tuple(eye), tuple(look), W, H), W, H,
+                                flags=esc.ESC_RENDER_EXACT_ONLY)
+        assert_bit_equal(exact, ref, f"exact-only/{case}/{len(lights)} lights")
+        assert ref.sum() > 0
+
+
 def test_mixed_triangles_and_spheres(esc, renderer):
     d = ol.load_dump("two")
     rng = np.random.default_rng(5)
@@ -379,6 +462,41 @@ def test_bench_two_ranks_gloo_on_one_gpu(tmp_path, gather):
     assert ("u8" if gather == "auto" else "fp32") in out["config"]["gather"]
     assert out["config"]["primary_rays_per_frame"] == 640 * 360
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+
+
+@pytest.mark.parametrize("use_rccl", [True, False])
+def test_native_multi_gpu_entry_on_one_device(esc, renderer, use_rccl):
+    """esc_multi_* / esc_render_frame_multi_rccl: the single-process entry a
+    C++ host uses.  One GPU here, so the communicator has one rank and the exchange step has no
+    peer -- what runs is dlopen(librccl) + ncclCommInitAll/Destroy, the strip render, the padded
+    gather layout, k_assemble_strips and the copy back; the N-rank partition itself is the
+    esc_render_strips one (test_strips_gather_assemble covers worlds 1/2/3/8)."""
+    sc, d = synthetic_dict(esc, "c3", 300)
+    eye, look = esc.synthetic_view()
+    W, H = 200, 117  # ragged last strip
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    full, full_u8 = renderer.render(cam, W, H, want_u8=True)
+    if use_rccl:
+        assert esc.rccl_available()
+    m = esc.MultiRenderer(1, use_rccl=use_rccl)
+    m.upload(sc)
+    img, ms, dptr = m.render(cam, W, H)
+    assert_bit_equal(img, full, "esc_multi_render fp32")
+    assert ms[0] > 0 and dptr
+    u8, _, _ = m.render(cam, W, H, gather_u8=True)
+    assert np.array_equal(u8, full_u8)
+    bvh, _, _ = m.render(cam, W, H, stage=esc.ESC_STAGE_BVH)
+    assert_bit_equal(bvh, full, "esc_multi_render through the BVH")
+    m.close()
+    with pytest.raises(esc.EscError):  # one communicator rank per device: 2 > device count here
+        esc.MultiRenderer(2, use_rccl=use_rccl)
+    with pytest.raises(esc.EscError):
+        esc.MultiRenderer(1, device_ids=[5], use_rccl=use_rccl)
+    if use_rccl:
+        img2, u82, ms2 = esc.render_multi_rccl(sc, cam, W, H, 1, want_u8=True)
+        assert_bit_equal(img2, full, "esc_render_frame_multi_rccl")
+        assert np.array_equal(u82, full_u8)
 
 
 def test_trace_drop_in(esc, renderer):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(esc):
     header = open(os.path.join(ROOT, "include", "esctp1_rt.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(esc_[a-z0-9_]+|trace)\s*\(", header))
-    declared -= {"esc_scene", "esc_context", "esc_flat_scene"}
+    declared -= {"esc_scene", "esc_context", "esc_flat_scene", "esc_multi"}
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
     lib = _capi.load()
     for name in declared:
@@ -35,6 +35,26 @@ def test_library_exports_every_declared_symbol(esc):
                         text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln}
     assert declared <= exported
+
+
+def test_multi_gpu_entry_without_a_gpu_fails_loudly(esc):
+    """esc_multi_create / esc_render_frame_multi_rccl on a host without a GPU: ESC_ERR_NO_DEVICE,
+    never a CPU render; the RCCL probe itself must not need a device."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the GPU-less container")
+    from esctp1raytracer_amd import _capi
+    assert esc.rccl_available() in (True, False)
+    with pytest.raises(esc.EscError) as e:
+        esc.MultiRenderer(2)
+    assert e.value.code == _capi.ESC_ERR_NO_DEVICE
+    sc = esc.Scene.synthetic("c2", 10)
+    cam = esc.Camera.for_image((0, 3, 6), (0, 2, -8), 64, 48)
+    with pytest.raises(esc.EscError) as e:
+        esc.render_multi_rccl(sc, cam, 64, 48, 2)
+    assert e.value.code == _capi.ESC_ERR_NO_DEVICE
+    with pytest.raises(esc.EscError):
+        esc.MultiRenderer(0)
 
 
 def test_struct_layouts_match_ispc_headers():
