@@ -882,33 +882,43 @@ DEVINL int anyhit_sph_pairs_filter(FetchF recf, FetchE rece, int n_rec, int base
                                    const RayF &rf, Any &a) {
   int swept = 0;
   const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
-  auto exact4 = [&](int k, int nrec) { // records k .. k+nrec-1 (nrec <= 4), index order
-    for (int j = 0; j < nrec; j += 2) {
-      const int k1 = min(k + j + 1, k + nrec - 1);
-      const PairG R[2] = {rece(k + j), rece(k1)};
-      v2f b[2], q[2];
-      pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+  auto exact2 = [&](int k, int nrec) { // records k, k+1 (nrec <= 2): the reference arithmetic
+    const PairG R[2] = {rece(k), rece(k + nrec - 1)};
+    v2f b[2], q[2];
+    pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+    // most filter candidates are margin, not hits: skip the accept code unless a disc is >= 0
+    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                      __float_as_int(q[1].y));
+    if (!ANY_LANE_RARE(m >= 0)) return;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (j + i >= nrec) break;
+    for (int i = 0; i < 2; ++i) {
+      if (i >= nrec) break;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float t2;
-          if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2)) {
-            a.tocc = t2;
-            a.kocc = base + 2 * (k + j + i) + c;
-            a.tb = 0.f;
-          }
+      for (int c = 0; c < 2; ++c) {
+        float t2;
+        if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2)) {
+          a.tocc = t2;
+          a.kocc = base + 2 * (k + i) + c;
+          a.tb = 0.f;
         }
       }
     }
   };
+  auto exact4 = [&](int k, int nrec) { // records k .. k+nrec-1 (nrec <= 4), index order
+    for (int j = 0; j < nrec; j += 2) exact2(k + j, min(2, nrec - j));
+  };
   auto test4 = [&](const PairF(&R)[4], int k) {
     v2f q[4];
     pair4_any_filter_pk(R, rf, q);
-    const int m = max_bits8(q, -1);
+    const int m01 = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                        __float_as_int(q[1].y));
+    const int m23 = max(max3i(__float_as_int(q[2].x), __float_as_int(q[2].y), __float_as_int(q[3].x)),
+                        __float_as_int(q[3].y));
     // a decided / dead lane (tb == 0) may still raise the flag; the exact code accepts nothing for it
-    if (ANY_LANE_RARE(m >= 0)) exact4(k, 4);
+    if (ANY_LANE_RARE(max(m01, m23) >= 0)) {
+      if (__builtin_amdgcn_ballot_w64(m01 >= 0)) exact2(k, 2);     // index order: records k, k+1
+      if (__builtin_amdgcn_ballot_w64(m23 >= 0)) exact2(k + 2, 2); // then k+2, k+3
+    }
   };
   for (int k0 = 0; k0 < n_rec; k0 += kFilterExitRecords) {
     if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return swept;

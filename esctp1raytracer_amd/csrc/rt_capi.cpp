@@ -34,6 +34,9 @@ extern "C" int esc_launch_bin_light(const esc::LightBins *g, const float *light_
                                     hipStream_t stream);
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px,
                                  hipStream_t stream, hipEvent_t between);
+extern "C" int esc_launch_shade_queue(const esc::RenderParams *p, int li, int last, const int *segs,
+                                      int n_segs, uint32_t *ctl, int n_wg, hipStream_t stream);
+extern "C" int esc_launch_primary_only(const esc::RenderParams *p, int px, hipStream_t stream);
 extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t rank_pitch_bytes,
                                    int n_ranks, int H, int strip_rows, size_t row_bytes,
                                    hipStream_t stream);
@@ -97,6 +100,13 @@ struct esc_context {
   bool accel_valid = false;
   esc::OriginBounds accel_ob{};
   esc_accel_info accel_info{};
+  // queue form of the shadow pass (rt_device.h ShadeQueue): grow-only scratch
+  void *d_sq = nullptr;
+  size_t sq_pixels = 0; // pixels the scratch is sized for
+  int sq_lights = 0;
+  uint32_t *d_sq_ctl = nullptr;
+  size_t sq_ctl_words = 0;
+  int n_cu = 0;
   // ESC_RENDER_TIME_KERNELS: events around / between the two frame kernels of the last frame
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool ev_valid = false;
@@ -537,7 +547,7 @@ void esc_context_destroy(esc_context *ctx) {
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
                   ctx->d_sph2,   ctx->d_sph2_p, ctx->d_sph_f, ctx->d_sph2_f,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
-                  ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits,
+                  ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits, ctx->d_sq, ctx->d_sq_ctl,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
                   ctx->d_bvh_sph_nodes, ctx->d_bvh_sph_blocks, ctx->d_bvh_sph_order,
                   ctx->d_bvh_tri_blocks_p, ctx->d_bvh_sph_blocks_p,
@@ -677,6 +687,115 @@ int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle
 } // extern "C"
 
 namespace {
+
+constexpr int kQueueMinPrims = 2048; // below this the fused k_shade is used
+constexpr int kQueueMaxSegs = 48;
+constexpr int kQueueFewTris = 64;   // this few triangles ride along with the first sphere segment
+
+// segments of occlusion()'s primitive list: triangles first (index order), then sphere pair
+// records.  Short segments at the start, where rays retire fastest per primitive; the length is
+// raised when the list would need more than kQueueMaxSegs launches.  $ESC_QUEUE_SEG=<records>
+// sets the length of the sphere segments (tuning).
+void queue_segments(int n_tri, int n_sph, std::vector<int> &segs) {
+  segs.clear();
+  auto cut = [&](bool tris, int n, int first_len, int steady_len, int align) {
+    int len = first_len, k = 0, made = 0;
+    const int budget = kQueueMaxSegs / 2;
+    while (k < n) {
+      int left_segs = budget - made;
+      int want = (made < 2) ? len : steady_len;
+      if (left_segs <= 1) want = n - k;
+      else want = std::max(want, (n - k + left_segs - 1) / left_segs);
+      want = (want + align - 1) / align * align;
+      const int c = std::min(want, n - k);
+      const int seg[4] = {tris ? k : 0, tris ? c : 0, tris ? 0 : k, tris ? 0 : c};
+      segs.insert(segs.end(), seg, seg + 4);
+      k += c;
+      made++;
+    }
+  };
+  static const int env_seg = [] {
+    const char *v = std::getenv("ESC_QUEUE_SEG");
+    return v ? std::max(4, std::atoi(v)) : 0;
+  }();
+  const int n_rec = (n_sph + 1) / 2;
+  const bool merge_tris = n_tri > 0 && n_tri <= kQueueFewTris && n_rec > 0;
+  if (n_tri > 0 && !merge_tris) cut(true, n_tri, 256, 1024, 2);
+  const size_t first_sph = segs.size();
+  if (n_rec > 0) cut(false, n_rec, env_seg ? env_seg : 256, env_seg ? env_seg : 512, 4);
+  if (merge_tris) { // a floor and a light are not worth a pass over every ray of their own
+    segs[first_sph + 0] = 0;
+    segs[first_sph + 1] = n_tri;
+  }
+}
+
+int render_shade_queue(esc_context *ctx, esc::RenderParams &p, int px, hipEvent_t between) {
+  const size_t npx = (size_t)p.n_local_rows * p.W;
+  if (npx > 0xfffffff0ull) {
+    set_error("render: band too large for 32-bit pixel ids");
+    return ESC_ERR_INVALID;
+  }
+  const size_t qcap = (npx + 63) / 64 * 64 + 64 * 4096; // ids per queue: every pixel + one partly
+                                                         // filled chunk per workgroup
+  const bool multi = p.n_lights > 1;
+  // one allocation: rays | normals | q0 | q1 | state
+  const size_t off_rays = 0, off_nrm = off_rays + npx * sizeof(esc::ShadowRay),
+               off_q0 = off_nrm + npx * sizeof(esc::ShadeNormal), off_q1 = off_q0 + qcap * 4,
+               off_state = off_q1 + qcap * 4, total = off_state + (multi ? npx * 16 : 0);
+  if (ctx->sq_pixels < npx || (multi && ctx->sq_lights < 2)) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // an earlier frame may still use the old scratch
+    if (ctx->d_sq) HIP_TRY(hipFree(ctx->d_sq));
+    ctx->d_sq = nullptr;
+    ctx->sq_pixels = 0;
+    HIP_TRY(hipMalloc(&ctx->d_sq, total));
+    ctx->sq_pixels = npx;
+    ctx->sq_lights = multi ? 2 : 1;
+  }
+  if (!ctx->n_cu) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    ctx->n_cu = std::max(1, prop.multiProcessorCount);
+  }
+  char *base = (char *)ctx->d_sq;
+  // offsets are computed for THIS band (<= the allocation: the layout only shrinks with npx)
+  p.sq.rays = (esc::ShadowRay *)(base + off_rays);
+  p.sq.nrm = (esc::ShadeNormal *)(base + off_nrm);
+  p.sq.q[0] = (uint32_t *)(base + off_q0);
+  p.sq.q[1] = (uint32_t *)(base + off_q1);
+  p.sq.state = multi ? (float *)(base + off_state) : nullptr;
+  std::vector<int> segs;
+  queue_segments(p.n_tri, p.n_sph, segs);
+  const int n_segs = (int)segs.size() / 4;
+  const size_t ctl_words = (size_t)p.n_lights * n_segs * 2;
+  if (ctx->sq_ctl_words < ctl_words) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_sq_ctl) HIP_TRY(hipFree(ctx->d_sq_ctl));
+    ctx->d_sq_ctl = nullptr;
+    ctx->sq_ctl_words = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->d_sq_ctl, ctl_words * 4));
+    ctx->sq_ctl_words = ctl_words;
+  }
+  p.sq.ctl = ctx->d_sq_ctl;
+  HIP_TRY(hipMemsetAsync(ctx->d_sq_ctl, 0, ctl_words * 4, ctx->stream));
+  int e = esc_launch_primary_only(&p, px, ctx->stream);
+  if (e) {
+    set_error(std::string("k_primary launch: ") + hipGetErrorString((hipError_t)e));
+    return ESC_ERR_HIP;
+  }
+  if (between) HIP_TRY(hipEventRecord(between, ctx->stream));
+  // persistent-style grid of the segment kernels: 8 workgroups of 4 waves per CU fill every SIMD
+  // (8 waves each); more would only queue behind them
+  const int n_wg = std::min(4096, ctx->n_cu * 8);
+  for (int li = 0; li < p.n_lights; li++) {
+    e = esc_launch_shade_queue(&p, li, li == p.n_lights - 1, segs.data(), n_segs,
+                               ctx->d_sq_ctl + (size_t)li * n_segs * 2, n_wg, ctx->stream);
+    if (e) {
+      set_error(std::string("shadow-queue kernel launch: ") + hipGetErrorString((hipError_t)e));
+      return ESC_ERR_HIP;
+    }
+  }
+  return ESC_OK;
+}
 
 // the one place a frame kernel is launched from: local row lr (ascending h) maps to image row
 // h0 + (lr / strip_rows) * strip_step + lr % strip_rows
@@ -849,7 +968,25 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       if (!ev) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   }
-  int e = esc_launch_render(&p, stage, px, ctx->stream, timed ? ctx->ev[1] : nullptr);
+  int e;
+  // Brute force with shadows over a long primitive list: the queue form of the shadow pass
+  // (global compaction of undecided rays between segments).  Short lists keep the fused k_shade
+  // (its per-workgroup re-packing costs no extra launches); $ESC_SHADE=wg|queue overrides.
+  static const int shade_env = [] {
+    const char *v = std::getenv("ESC_SHADE");
+    return !v ? 0 : (std::strcmp(v, "wg") == 0 ? 1 : (std::strcmp(v, "queue") == 0 ? 2 : 0));
+  }();
+  const bool queue_form =
+      stage == 1 && p.shadows && p.n_lights > 0 && shade_env != 1 &&
+      (shade_env == 2 || opts->stage == ESC_STAGE_AUTO) &&
+      (shade_env == 2 || (int64_t)p.n_tri + p.n_sph >= kQueueMinPrims);
+  if (queue_form) {
+    int rc = render_shade_queue(ctx, p, px, timed ? ctx->ev[1] : nullptr);
+    if (rc) return rc;
+    e = 0;
+  } else {
+    e = esc_launch_render(&p, stage, px, ctx->stream, timed ? ctx->ev[1] : nullptr);
+  }
   if (timed && !e) {
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     ctx->ev_valid = true;

@@ -115,6 +115,47 @@ struct HitPlanes {
 };
 
 // ---------------------------------------------------------------------------------------
+// Queue form of the shadow pass (rt_kernels.hip k_shadow_setup / k_anyhit_segment /
+// k_shade_finish).  occlusion() (main.cpp:314-329) walks the primitive list in index order and
+// stops at the first hit, so rays retire all along the list; a wave that keeps its 64 rays from
+// start to end idles more and more lanes.  Here the list is cut into segments, one kernel launch
+// each, and between segments the rays still looking are compacted ACROSS THE WHOLE BAND into a
+// queue of pixel ids, so every wave of every segment starts full and no retired ray holds a wave
+// slot.  Every ray still meets the primitives in index order: first occluder, its t2 (quirk S3)
+// and the image are unchanged.
+// ---------------------------------------------------------------------------------------
+struct alignas(16) ShadowRay { // one per pixel of the band, indexed by band-local pixel
+  float ox, oy, oz; // origin (main.cpp:757 `hit`); once decided: ox = the occluder's t2
+  float tb;         // bound len - eps (main.cpp:764); 0 = no ray, or decided
+  float lx, ly, lz; // unit direction (main.cpp:766)
+  int32_t kocc;     // -1, or the first occluder's index in (triangles, spheres) order
+};
+struct alignas(16) ShadeNormal { // main.cpp:723-738 result, kept from setup to finish
+  float nx, ny, nz;
+  int32_t mi; // material index
+};
+constexpr uint32_t kQueueInvalid = 0xffffffffu; // pad entry of a partly filled 64-id chunk
+struct ShadeQueue {
+  ShadowRay *rays;    // [n_pixels]
+  ShadeNormal *nrm;   // [n_pixels]
+  uint32_t *q[2];     // ping-pong queues of pixel ids, in chunks of 64
+  uint32_t *ctl;      // per (light, segment): [0] chunks appended to the segment's OUTPUT queue,
+                      // [1] work-fetch cursor; zeroed at the start of every frame
+  float *state;       // n_lights > 1 only: planes t, r, g, b carried from light to light
+};
+struct SegArgs { // one launch of k_anyhit_segment
+  const uint32_t *qin;        // nullptr: every pixel of the band in order (first segment)
+  const uint32_t *in_chunks;  // chunks in qin (device); unused with qin == nullptr
+  uint32_t n_identity_chunks; // chunks when qin == nullptr
+  uint32_t n_pixels;
+  uint32_t *qout;             // nullptr: last segment (survivors are simply not occluded)
+  uint32_t *out_chunks;
+  uint32_t *cursor;
+  int32_t tri_first, tri_count; // triangles of this segment (tested first: index order) ...
+  int32_t rec_first, rec_count; // ... then its sphere PAIR records; either count may be 0
+};
+
+// ---------------------------------------------------------------------------------------
 // acceleration structure (ESC_STAGE_BVH; the reference's --bvh intent, main.cpp:98-171,
 // aabb.cpp:67-110).  Binary BVH whose node holds the boxes of BOTH children, 64 B = one
 // s_load_dwordx16: a whole wavefront walks the tree together (wave-uniform node index, node in
@@ -225,6 +266,7 @@ struct RenderParams {
   uint8_t *out_u8;  // band-local, may be null
   // kCounterSets replicas of {primary, hit, shadow rays, any-hit tests, 4 spare}, 64 B each
   unsigned long long *counters;
+  ShadeQueue sq;                // queue form of the shadow pass (brute force, large scenes)
   HitPlanes hits;               // band-local, n_local_rows * W pixels (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only
   BinGrid bins;                 // ESC_STAGE_BVH only; hdr == nullptr: no bins, walk the tree

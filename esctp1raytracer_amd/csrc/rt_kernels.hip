@@ -172,6 +172,97 @@ template <int PX> struct Tile {
   }
 };
 
+// ---- counters: ballot + popcount per wave, summed per workgroup in LDS, then ONE global atomic
+// per counter per workgroup into one of kCounterSets replicas (each on its own cache line).
+// 130k waves adding to four words of one line took longer than shading itself (4.7 ms).
+// Called by all 256 threads (barriers inside).  count_pixels: also add primary rays / hit pixels.
+DEVINL void emit_counters(const RenderParams &p, int tid, int lane, bool inside, bool has_hit,
+                          uint32_t n_shadow, unsigned long long n_any,
+                          unsigned long long lane_tests_wave, bool count_pixels) {
+  if (!p.counters) return;
+  __shared__ unsigned long long wg_cnt[5];
+  if (tid < 5) wg_cnt[tid] = 0ull;
+  __syncthreads();
+  const uint32_t ni = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(inside));
+  const uint32_t nh = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_hit));
+  uint32_t ns = n_shadow;
+  unsigned long long na = n_any;
+  for (int o = 32; o > 0; o >>= 1) {
+    ns += __shfl_down(ns, o);
+    na += __shfl_down(na, o);
+  }
+  if (lane == 0) {
+    if (count_pixels) {
+      atomicAdd(&wg_cnt[0], (unsigned long long)ni);
+      atomicAdd(&wg_cnt[1], (unsigned long long)nh);
+    }
+    atomicAdd(&wg_cnt[2], (unsigned long long)ns);
+    atomicAdd(&wg_cnt[3], na);
+    atomicAdd(&wg_cnt[4], lane_tests_wave);
+  }
+  __syncthreads();
+  if (tid < 5 && wg_cnt[tid])
+    atomicAdd(&p.counters[(blockIdx.x % kCounterSets) * 8 + tid], wg_cnt[tid]);
+}
+
+// ---- framebuffer: transpose the tile through LDS so each store instruction writes
+// consecutive dwords of one image row (12-byte pixels would otherwise stride the lanes).
+// lds_px: 32 * kTileH * 3 floats.  Called by all 256 threads.
+DEVINL void write_tile(const RenderParams &p, const Tile<1> &T, int tid, float r, float g, float b,
+                       bool inside, float *lds_px) {
+  constexpr int TW = 32;
+  const int rows = p.n_local_rows;
+  const int lr = T.lr0 + T.ly, w = T.w0 + T.lx0;
+  const int lx = T.lx0, ly = T.ly, w0 = T.w0, lr0 = T.lr0;
+  const bool full_tile = (w0 + TW <= p.W) && (lr0 + kTileH <= rows) && (T.h_tile + kTileH <= p.H);
+  if (p.out_f32) {
+    if (full_tile) {
+      const int li = (ly * TW + lx) * 3;
+      lds_px[li + 0] = r;
+      lds_px[li + 1] = g;
+      lds_px[li + 2] = b;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i; // 0 .. 767
+        const int row = idx / (TW * 3), col = idx % (TW * 3);
+        const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + col;
+        p.out_f32[o] = lds_px[idx];
+      }
+    } else if (inside) {
+      const size_t o = ((size_t)lr * p.W + w) * 3;
+      p.out_f32[o + 0] = r;
+      p.out_f32[o + 1] = g;
+      p.out_f32[o + 2] = b;
+    }
+  }
+  if (p.out_u8) { // main.cpp:676-682 clamp > 1, int(c * 255)
+    const float cr = (r > 1.f) ? 1.f : r, cg = (g > 1.f) ? 1.f : g, cb = (b > 1.f) ? 1.f : b;
+    const uint8_t qr = (uint8_t)(int)(cr * 255.f), qg = (uint8_t)(int)(cg * 255.f),
+                  qb = (uint8_t)(int)(cb * 255.f);
+    if (full_tile && (p.W & 3) == 0) {
+      __syncthreads(); // lds_px reuse
+      unsigned char *lb = reinterpret_cast<unsigned char *>(lds_px);
+      const int li = (ly * TW + lx) * 3;
+      lb[li + 0] = qr;
+      lb[li + 1] = qg;
+      lb[li + 2] = qb;
+      __syncthreads();
+      constexpr int ROW_DW = TW * 3 / 4; // dwords per tile row
+      if (tid < ROW_DW * kTileH) {
+        const int row = tid / ROW_DW, col = tid % ROW_DW;
+        const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + (size_t)col * 4;
+        *reinterpret_cast<uint32_t *>(p.out_u8 + o) = reinterpret_cast<const uint32_t *>(lb)[tid];
+      }
+    } else if (inside) {
+      const size_t o = ((size_t)lr * p.W + w) * 3;
+      p.out_u8[o + 0] = qr;
+      p.out_u8[o + 1] = qg;
+      p.out_u8[o + 2] = qb;
+    }
+  }
+}
+
 // main.cpp:709-713 + camera.h:31-34
 DEVINL f3 primary_dir(const RenderParams &p, int w, int h) {
   const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
@@ -523,83 +614,242 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
     }
   }
 
-  // ---- counters: ballot + popcount per wave, summed per workgroup in LDS, then ONE global atomic
-  // per counter per workgroup into one of kCounterSets replicas (each on its own cache line).
-  // 130k waves adding to four words of one line took longer than shading itself (4.7 ms).
-  if (p.counters) {
-    __shared__ unsigned long long wg_cnt[5];
-    if (tid < 5) wg_cnt[tid] = 0ull;
-    __syncthreads();
-    const uint32_t ni = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(inside));
-    const uint32_t nh = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_hit));
-    uint32_t ns = n_shadow;
-    unsigned long long na = n_any;
-    for (int o = 32; o > 0; o >>= 1) {
-      ns += __shfl_down(ns, o);
-      na += __shfl_down(na, o);
-    }
-    if (lane == 0) {
-      atomicAdd(&wg_cnt[0], (unsigned long long)ni);
-      atomicAdd(&wg_cnt[1], (unsigned long long)nh);
-      atomicAdd(&wg_cnt[2], (unsigned long long)ns);
-      atomicAdd(&wg_cnt[3], na);
-      atomicAdd(&wg_cnt[4], (unsigned long long)n_swept * 64ull);
-    }
-    __syncthreads();
-    if (tid < 5 && wg_cnt[tid])
-      atomicAdd(&p.counters[(blockIdx.x % kCounterSets) * 8 + tid], wg_cnt[tid]);
-  }
+  emit_counters(p, tid, lane, inside, has_hit, n_shadow, n_any, (unsigned long long)n_swept * 64ull,
+                true);
+  write_tile(p, T, tid, r, g, b, inside, lds_px);
+}
 
-  // ---- framebuffer: transpose the tile through LDS so each store instruction writes
-  // consecutive dwords of one image row (12-byte pixels would otherwise stride the lanes).
-  const int lx = T.lx0, ly = T.ly, w0 = T.w0, lr0 = T.lr0;
-  const bool full_tile = (w0 + TW <= p.W) && (lr0 + kTileH <= rows) && (T.h_tile + kTileH <= p.H);
-  if (p.out_f32) {
-    if (full_tile) {
-      const int li = (ly * TW + lx) * 3;
-      lds_px[li + 0] = r;
-      lds_px[li + 1] = g;
-      lds_px[li + 2] = b;
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int idx = tid + 256 * i; // 0 .. 767
-        const int row = idx / (TW * 3), col = idx % (TW * 3);
-        const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + col;
-        p.out_f32[o] = lds_px[idx];
+// ---------------------------------------------------------------------------------------
+// Queue form of the shadow pass (rt_device.h ShadeQueue): per light
+//     k_shadow_setup  ->  k_anyhit_segment x (segments of the primitive list)  ->  k_shade_finish
+// The arithmetic of every ray is the fused k_shade's, statement for statement; only WHERE a ray is
+// tested (which wave, next to which other rays) differs.
+// ---------------------------------------------------------------------------------------
+
+// main.cpp:723-766 for light `li`: normal of the hit (first light only), light sample, shadow ray.
+template <bool MULTI>
+__global__ void __launch_bounds__(256) k_shadow_setup(const RenderParams p, int li) {
+  const Tile<1> T(p);
+  const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly, w = T.w0 + T.lx0;
+  const bool inside = (lr < p.n_local_rows) && (h < p.H) && (w < p.W);
+  if (!inside) return;
+  const size_t npx = (size_t)p.n_local_rows * p.W;
+  const size_t px = (size_t)lr * p.W + w;
+  const int32_t idx = p.hits.idx[px];
+  if (idx < 0) return; // no record for a miss: the first segment reads the idx plane itself
+  const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
+  float t = (MULTI && li > 0) ? p.sq.state[px] : p.hits.t[px];
+  if (li == 0) { // main.cpp:723-738, once per pixel (per-lane gathers)
+    f3 N;
+    int mi;
+    if (idx < p.n_tri) {
+      const DevTri Tr = p.tri[idx];
+      N = normalize(cross(ld3(Tr.e1), ld3(Tr.e2))); // :728-731
+      mi = Tr.geom;
+      if (p.mat[mi].has_normals) { // :733-738 with u == 0 (quirk S1)
+        const DevTriN Q = p.tri_n[idx];
+        const float u = 0.f, v = p.hits.v[px];
+        N = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
       }
-    } else if (inside) {
-      const size_t o = ((size_t)lr * p.W + w) * 3;
-      p.out_f32[o + 0] = r;
-      p.out_f32[o + 1] = g;
-      p.out_f32[o + 2] = b;
+    } else {
+      const int k = idx - p.n_tri;
+      const DevSph S = p.sph[k];
+      N = normalize((origin + primary_dir(p, w, h) * t) - mk(S.cx, S.cy, S.cz)); // extension
+      mi = p.sph_mat[k];
+    }
+    ShadeNormal nm;
+    nm.nx = N.x;
+    nm.ny = N.y;
+    nm.nz = N.z;
+    nm.mi = mi;
+    p.sq.nrm[px] = nm;
+  }
+  const DevLight Lt = p.lights[li];
+  const uint32_t face = (p.face_mode == 0) ? (uint32_t)p.fixed_face
+                        : (Lt.n_faces == 1) ? 0u
+                                            : face_hash(p.seed, (uint32_t)(h * p.W + w), (uint32_t)li,
+                                                        (uint32_t)Lt.n_faces);
+  const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
+  const f3 ro = origin + primary_dir(p, w, h) * (t - FLT_EPSILON);     // :757-758
+  f3 rL = P - ro;                                                        // :759
+  const float len = length(rL);                                          // :761
+  t = len - FLT_EPSILON;                                                 // :764
+  rL = normalize(rL);                                                    // :766
+  ShadowRay R;
+  R.ox = ro.x;
+  R.oy = ro.y;
+  R.oz = ro.z;
+  R.tb = (t > 0.f) ? t : 0.f; // dead rays carry tb = 0
+  R.lx = rL.x;
+  R.ly = rL.y;
+  R.lz = rL.z;
+  R.kocc = -1;
+  p.sq.rays[px] = R;
+  if (MULTI) p.sq.state[px] = t; // what main.cpp:764 leaves in `t` for the next light
+  (void)npx;
+}
+
+// One segment of occlusion()'s loop (main.cpp:314-329) for every ray still looking.
+// Workgroups pull batches of 64-ray chunks from the input queue (one atomic per batch), each wave
+// sweeps the segment for its chunks, decided rays write their occluder back to their ShadowRay,
+// undecided ones are staged in LDS and leave as full chunks of the output queue (one atomic per
+// flush).  Every workgroup leaves the loop when the cursor passes the end: nothing waits on
+// another workgroup.
+constexpr int kSegBatch = 2; // chunks per wave per fetch
+template <bool HAS_TRI, bool HAS_SPH>
+__global__ void __launch_bounds__(256) k_anyhit_segment(const RenderParams p, const SegArgs a) {
+  __shared__ uint32_t stage[64 + 4 * kSegBatch * 64];
+  __shared__ uint32_t n_staged, batch0, out_base;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const uint32_t n_chunks = a.qin ? *a.in_chunks : a.n_identity_chunks;
+  if (tid == 0) n_staged = 0;
+  int swept = 0; // primitives this wave swept (x64 = lane-tests)
+  for (;;) {
+    __syncthreads(); // n_staged / stage of the previous round; batch0 readers of the previous round
+    if (tid == 0) batch0 = atomicAdd(a.cursor, 4u * kSegBatch);
+    __syncthreads();
+    const uint32_t c0 = batch0;
+    if (c0 >= n_chunks) break; // workgroup-uniform
+#pragma unroll 1
+    for (int j = 0; j < kSegBatch; ++j) {
+      const uint32_t c = c0 + (uint32_t)(wave * kSegBatch + j);
+      if (c >= n_chunks) break; // wave-uniform
+      uint32_t id;
+      bool valid;
+      if (a.qin) {
+        id = a.qin[(size_t)c * 64 + lane];
+        valid = id != kQueueInvalid;
+      } else {
+        id = c * 64u + (uint32_t)lane;
+        valid = id < a.n_pixels && p.hits.idx[id] >= 0;
+      }
+      Any aa[1];
+      aa[0].tb = 0.f;
+      aa[0].tocc = 0.f;
+      aa[0].kocc = -1;
+      f3 so = mk(0.f, 0.f, 0.f), sL = so;
+      if (valid) {
+        const ShadowRay R = p.sq.rays[id];
+        so = mk(R.ox, R.oy, R.oz);
+        sL = mk(R.lx, R.ly, R.lz);
+        aa[0].tb = R.tb;
+      }
+      if (__builtin_amdgcn_ballot_w64(aa[0].tb > 0.f)) {
+        if (HAS_TRI) {
+          const V3<float> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
+          swept += a.tri_count; // upper bound: exits inside a segment are not subtracted
+          anyhit_tri<float, 1>(SmemFetch<DevTri>{p.tri + a.tri_first}, a.tri_count, a.tri_first, sov,
+                               sLv, aa);
+        }
+        if (HAS_SPH) {
+          if (p.use_filter) {
+            const RayF rf = make_ray_filter(so, sL, p.shadow_center);
+            swept += 2 * anyhit_sph_pairs_filter(
+                             SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sph2_f) + a.rec_first},
+                             SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + a.rec_first},
+                             a.rec_count, p.n_tri + 2 * a.rec_first, so, sL, rf, aa[0]);
+          } else {
+            swept += 2 * anyhit_sph_pairs(
+                             SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + a.rec_first},
+                             a.rec_count, p.n_tri + 2 * a.rec_first, so, sL, aa[0]);
+          }
+        }
+      }
+      if (aa[0].kocc >= 0) { // decided: occlusion() returned true and wrote t2 through its reference
+        ShadowRay *R = p.sq.rays + id;
+        R->ox = aa[0].tocc;
+        R->tb = 0.f;
+        R->kocc = aa[0].kocc;
+      }
+      if (a.qout) {
+        const bool survive = aa[0].tb > 0.f;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(survive);
+        if (m) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&n_staged, (uint32_t)__popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (survive) stage[base + __popcll(m & ((1ull << lane) - 1ull))] = id;
+        }
+      }
+    }
+    if (a.qout) { // full chunks leave for the output queue, the remainder moves to the front
+      __syncthreads();
+      const uint32_t ns = n_staged, full = ns >> 6, rem = ns & 63u;
+      if (full) {
+        if (tid == 0) out_base = atomicAdd(a.out_chunks, full);
+        __syncthreads();
+        for (uint32_t i = tid; i < full * 64u; i += 256u) a.qout[(size_t)out_base * 64 + i] = stage[i];
+        const uint32_t keep = (tid < (int)rem) ? stage[full * 64u + tid] : 0u;
+        __syncthreads();
+        if (tid < (int)rem) stage[tid] = keep;
+        if (tid == 0) n_staged = rem;
+      }
     }
   }
-  if (p.out_u8) { // main.cpp:676-682 clamp > 1, int(c * 255)
-    const float cr = (r > 1.f) ? 1.f : r, cg = (g > 1.f) ? 1.f : g, cb = (b > 1.f) ? 1.f : b;
-    const uint8_t qr = (uint8_t)(int)(cr * 255.f), qg = (uint8_t)(int)(cg * 255.f),
-                  qb = (uint8_t)(int)(cb * 255.f);
-    if (full_tile && (p.W & 3) == 0) {
-      __syncthreads(); // lds_px reuse
-      unsigned char *lb = reinterpret_cast<unsigned char *>(lds_px);
-      const int li = (ly * TW + lx) * 3;
-      lb[li + 0] = qr;
-      lb[li + 1] = qg;
-      lb[li + 2] = qb;
+  if (a.qout) { // the break above is workgroup-uniform and follows a barrier: n_staged is settled
+    const uint32_t ns = n_staged;
+    if (ns) {
+      if (tid == 0) out_base = atomicAdd(a.out_chunks, 1u);
       __syncthreads();
-      constexpr int ROW_DW = TW * 3 / 4; // dwords per tile row
-      if (tid < ROW_DW * kTileH) {
-        const int row = tid / ROW_DW, col = tid % ROW_DW;
-        const size_t o = ((size_t)(lr0 + row) * p.W + w0) * 3 + (size_t)col * 4;
-        *reinterpret_cast<uint32_t *>(p.out_u8 + o) = reinterpret_cast<const uint32_t *>(lb)[tid];
-      }
-    } else if (inside) {
-      const size_t o = ((size_t)lr * p.W + w) * 3;
-      p.out_u8[o + 0] = qr;
-      p.out_u8[o + 1] = qg;
-      p.out_u8[o + 2] = qb;
+      if (tid < 64) a.qout[(size_t)out_base * 64 + tid] = (tid < (int)ns) ? stage[tid] : kQueueInvalid;
     }
   }
+  emit_counters(p, tid, lane, false, false, 0u, 0ull, (unsigned long long)swept * 64ull, false);
+}
+
+// main.cpp:768-789 for light `li` (+ the framebuffer after the last light)
+template <bool MULTI>
+__global__ void __launch_bounds__(256) k_shade_finish(const RenderParams p, int li, int last) {
+  __shared__ float lds_px[32 * kTileH * 3];
+  const Tile<1> T(p);
+  const int tid = threadIdx.x, lane = T.lane;
+  const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly, w = T.w0 + T.lx0;
+  const bool inside = (lr < p.n_local_rows) && (h < p.H) && (w < p.W);
+  const size_t npx = (size_t)p.n_local_rows * p.W;
+  const size_t px = inside ? (size_t)lr * p.W + w : 0;
+  const bool has_hit = inside && p.hits.idx[px] >= 0;
+  float r = 0.f, g = 0.f, b = 0.f; // vec3 default ctor, main.cpp:557-558
+  uint32_t n_shadow = 0;
+  unsigned long long n_any = 0;
+  if (has_hit) {
+    if (MULTI && li > 0) {
+      r = p.sq.state[npx + px];
+      g = p.sq.state[2 * npx + px];
+      b = p.sq.state[3 * npx + px];
+    }
+    const ShadowRay R = p.sq.rays[px];
+    n_shadow = 1u;
+    n_any = (R.kocc >= 0) ? (unsigned)(R.kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
+    if (R.kocc >= 0) {
+      if (MULTI) p.sq.state[px] = R.ox; // occlusion() wrote the occluder's t2 into t (quirk S3)
+    } else {                            // :772-773 `continue` otherwise
+      const ShadeNormal nm = p.sq.nrm[px];
+      const f3 N = mk(nm.nx, nm.ny, nm.nz), rL = mk(R.lx, R.ly, R.lz);
+      const float nl = (float)p.n_lights;
+      const float d = dot(N, rL); // :775
+      if (!(d <= 0.f)) {          // :777
+        const DevMat M = p.mat[nm.mi];                // :768
+        f3 c = ld3(M.ka) * 0.5f + ld3(M.ke);          // :769-770
+        if (nl != 1.f) c = c / nl;                    // x / 1.0f == x bit for bit
+        const f3 Hh = normalize((N + rL) * 2.f);      // :780
+        const float sp = powf(dot(N, Hh), M.Ns);
+        f3 ds = ld3(M.kd) * d + ld3(M.ks) * sp;       // :782-783
+        if (nl != 1.f) ds = ds / nl;
+        c = c + ds;
+        r += c.x;                                      // :786-788
+        g += c.y;
+        b += c.z;
+      }
+    }
+    if (MULTI && !last) {
+      p.sq.state[npx + px] = r;
+      p.sq.state[2 * npx + px] = g;
+      p.sq.state[3 * npx + px] = b;
+    }
+  }
+  emit_counters(p, tid, lane, inside, has_hit, n_shadow, n_any, 0ull, last != 0);
+  if (last) write_tile(p, T, tid, r, g, b, inside, lds_px);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -696,6 +946,55 @@ static void launch_primary(const esc::RenderParams *p, hipStream_t stream) {
   const int tiles_x = (p->W + tw - 1) / tw;
   const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
   hipLaunchKernelGGL((esc::k_primary<STAGE, V, NV>), dim3(tiles_x * tiles_y), dim3(256), 0, stream, *p);
+}
+
+// the queue form of the shadow pass for one light: setup, one launch per segment, finish.
+// segs: (tri_first, tri_count, rec_first, rec_count) per segment; ctl: this light's control words, 2 per segment, zeroed.
+extern "C" int esc_launch_shade_queue(const esc::RenderParams *p, int li, int last, const int *segs,
+                                      int n_segs, uint32_t *ctl, int n_wg, hipStream_t stream) {
+  const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
+  const int grid = ((p->W + 31) / 32) * tiles_y;
+  const bool multi = p->n_lights > 1;
+  if (multi)
+    hipLaunchKernelGGL((esc::k_shadow_setup<true>), dim3(grid), dim3(256), 0, stream, *p, li);
+  else
+    hipLaunchKernelGGL((esc::k_shadow_setup<false>), dim3(grid), dim3(256), 0, stream, *p, li);
+  const uint32_t n_pixels = (uint32_t)((size_t)p->n_local_rows * p->W);
+  for (int s = 0; s < n_segs; ++s) {
+    esc::SegArgs a;
+    a.qin = (s == 0) ? nullptr : p->sq.q[(s - 1) & 1];
+    a.in_chunks = (s == 0) ? nullptr : ctl + 2 * (s - 1);
+    a.n_identity_chunks = (n_pixels + 63u) / 64u;
+    a.n_pixels = n_pixels;
+    a.qout = (s == n_segs - 1) ? nullptr : p->sq.q[s & 1];
+    a.out_chunks = ctl + 2 * s;
+    a.cursor = ctl + 2 * s + 1;
+    a.tri_first = segs[4 * s + 0];
+    a.tri_count = segs[4 * s + 1];
+    a.rec_first = segs[4 * s + 2];
+    a.rec_count = segs[4 * s + 3];
+    if (a.tri_count && a.rec_count)
+      hipLaunchKernelGGL((esc::k_anyhit_segment<true, true>), dim3(n_wg), dim3(256), 0, stream, *p, a);
+    else if (a.tri_count)
+      hipLaunchKernelGGL((esc::k_anyhit_segment<true, false>), dim3(n_wg), dim3(256), 0, stream, *p, a);
+    else
+      hipLaunchKernelGGL((esc::k_anyhit_segment<false, true>), dim3(n_wg), dim3(256), 0, stream, *p, a);
+  }
+  if (multi)
+    hipLaunchKernelGGL((esc::k_shade_finish<true>), dim3(grid), dim3(256), 0, stream, *p, li, last);
+  else
+    hipLaunchKernelGGL((esc::k_shade_finish<false>), dim3(grid), dim3(256), 0, stream, *p, li, last);
+  return (int)hipGetLastError();
+}
+
+// the primary pass alone (the queue form launches its own shading kernels)
+extern "C" int esc_launch_primary_only(const esc::RenderParams *p, int px, hipStream_t stream) {
+  if (p->n_local_rows <= 0 || p->W <= 0) return 0;
+  using esc::v2f;
+  if (px == 1) launch_primary<esc::STAGE_SMEM, float, 1>(p, stream);
+  else if (px == 2) launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream);
+  else launch_primary<esc::STAGE_SMEM, v2f, 2>(p, stream);
+  return (int)hipGetLastError();
 }
 
 // stage: 1 SMEM, 2 LDS, 3 BVH (px ignored).  px: pixels per work-item of the primary pass (1, 2 or 4); the shade
