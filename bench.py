@@ -40,6 +40,41 @@ FP32_VALU_PEAK_TF = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
 F_SPHERE, F_TRI = 19, 51   # algorithmic flop per ray-primitive test, SURVEY.md 8(d)
 
 
+def source_stamp():
+    """sha256 over the device sources and build flags the committed rocprofv3 numbers belong to"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "esctp1raytracer_amd", "csrc", "*"))) + \
+        [os.path.join(ROOT, "Makefile")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(config):
+    """profiles/current.json: per-frame PMC numbers of the SHIPPED kernels (tools/summarize_prof.py
+    writes it, stamped with source_stamp()).  Returns None when it belongs to other sources --
+    a stale counter must never be passed off as this run's."""
+    path = os.path.join(ROOT, "profiles", "current.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        prof = json.load(f)
+    if prof.get("source_stamp") != source_stamp() or prof.get("config") != config:
+        return None
+    return prof
+
+
+# measured on this chip (tools/ubench/valu_rate.hip): cycles one SIMD needs per wave64 instruction
+# with several waves resident; packed = v_pk_mul/add/fma_f32 (two results per lane)
+CYC_PACKED, CYC_PLAIN = 4.1, 2.66
+# packed share of the VALU instructions in each hot loop (counted in the ISA, `make asm`)
+PACKED_SHARE = {"k_primary": 32 / 41, "k_shade": 32 / 37}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,6 +356,24 @@ def main():
         for k, v in rr.counters().items():
             cnt[k] += v
 
+    # per-kernel durations (HIP events recorded by the library between the frame's kernels):
+    # a few extra frames outside the timed region, one at a time
+    kernel_split = None
+    if world == 1 and a.stage != "bvh":
+        acc = [0.0, 0.0]
+        n_split = 3
+        for _ in range(n_split):
+            with torch.cuda.stream(st):
+                r.render_strips(cam, W, H, 0, 1, out_f32=None if use_u8 else local[0],
+                                out_u8=local[0] if use_u8 else None, strip_rows=S, shadows=shadows,
+                                stage=stage, flags=esc.ESC_RENDER_TIME_KERNELS)
+            ms = r.last_kernel_ms()
+            acc[0] += ms[0]
+            acc[1] += ms[1]
+        kernel_split = {"k_primary_ms": acc[0] / n_split, "k_shade_ms": acc[1] / n_split,
+                        "note": "k_shade_ms = everything after k_primary: the fused k_shade, or "
+                                "k_shadow_setup + k_anyhit_segment x segments + k_shade_finish"}
+
     # one un-pipelined frame: launch -> complete frame resident on rank 0
     fence()
     t1 = time.perf_counter()
@@ -376,11 +429,9 @@ def main():
         scene_bytes = n_sph * 32 + n_tri * 112 + (info["n_geometry"] + n_sph) * 64
         alg_bytes = frame_bytes + scene_bytes
         gbs = alg_bytes / (roof_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if world == 1 and a.config == "c4" and not a.prims and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+        prof = committed_profile(a.config) if (world == 1 and not a.prims and not a.width
+                                               and a.stage == "auto") else None
+        traffic = prof["hbm_bytes_per_frame"] if prof else None
         share = my_rows / H
         closest_flop = (primary / a.steps) * share * (n_tri * F_TRI + n_sph * F_SPHERE)
         f_any = (n_tri * F_TRI + n_sph * F_SPHERE) / max(n_tri + n_sph, 1)
@@ -429,19 +480,42 @@ def main():
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_source": (prof["source"] if prof else
+                                            "null: profiles/current.json is missing or was "
+                                            "measured on other sources (stamp mismatch)"),
                          "traffic_note": "algorithmic = fp32 framebuffer + scene tables (SURVEY.md "
-                                         "8(d)); measured traffic also holds the 16-byte hit record "
-                                         "per pixel that k_primary hands to k_shade (written and "
-                                         "read once: 2 x 132.7 MB at 4K), i.e. 366 MB expected, "
-                                         "373.7 MB measured; the kernels are VALU-bound, see "
-                                         "roofline_valu"},
+                                         "8(d)); measured traffic (rocprofv3 --pmc FETCH_SIZE / "
+                                         "WRITE_SIZE passes, fetch doubled per the gfx950 note) also "
+                                         "holds the hit planes k_primary hands over and the shadow-ray "
+                                         "queue; the kernels are VALU-bound, see roofline_valu"},
             "roofline_valu": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TF,
                               "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
                               "note": "algorithmic flop (19/sphere test, 51/triangle test) of the "
-                                      "tests the reference executes / kernel time; the peak counts "
-                                      "FMA as 2 flop and this kernel may not fuse (bit parity), so "
-                                      "0.5 is the ceiling"},
+                                      "tests the REFERENCE executes / kernel time.  Not an "
+                                      "executed-op rate: the kernels hoist per-primitive work and "
+                                      "run a 4- / 8-op FMA filter instead of the 7- / 16-op test for "
+                                      "all but the candidate pairs, so this can exceed 1; the "
+                                      "executed view is `kernels`"},
         }
+        if kernel_split is not None:
+            out["kernel_split"] = kernel_split
+            # executed-instruction view per kernel: VALU wave-instructions (committed rocprofv3
+            # SQ_INSTS_VALU, stamped) x measured issue cost / (kernel time x SIMDs x clock)
+            ks = {}
+            for name, ms_key in (("k_primary", "k_primary_ms"), ("k_shade", "k_shade_ms")):
+                ent = {"ms": kernel_split[ms_key]}
+                if prof and name in prof.get("valu_insts_per_frame", {}):
+                    insts = prof["valu_insts_per_frame"][name]
+                    share = PACKED_SHARE[name]
+                    cyc = share * CYC_PACKED + (1 - share) * CYC_PLAIN
+                    clock_ghz = prof.get("clock_ghz", 2.4)
+                    avail = ent["ms"] * 1e-3 * clock_ghz * 1e9 * 1024  # SIMD-cycles
+                    ent.update({"valu_insts": insts, "packed_share": share,
+                                "cycles_per_inst_at_full_issue": cyc, "clock_ghz": clock_ghz,
+                                "issue_frac": insts * cyc / avail,
+                                "lane_ops_per_s": insts * 64 * (1 + share) / (ent["ms"] * 1e-3)})
+                ks[name] = ent
+            out["kernels"] = ks
         if pipelined is not None:
             pipelined["value"] = rays / a.steps / (pipelined["ms_per_step"] * 1e-3) / 1e6
             out["pipelined"] = pipelined

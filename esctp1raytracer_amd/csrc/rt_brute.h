@@ -542,6 +542,189 @@ DEVINL void closest_sph_primary_filter(FetchF recf, FetchE rece, int n, int base
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Triangle FILTERS.  ray_triangle.h's accept needs (with s = sign(det), all in its own rounded
+// arithmetic):  s*un > 0,  s*vn > 0,  s*(un + vn) <= |det| (1 + 4u)   -- from u2 >= eps, v2 >= eps,
+// u2 + v2 <= 1 -- and |un|, |vn| <= |det| (1 + 4u).  In product form, free of sign logic:
+//     un*det > 0,   vn*det > 0,   det*(det - un - vn) >= -4u det^2.
+// The filter evaluates det', un', vn' as FMA dot products with hoisted cross products (rt_device.h
+// DevTriF / DevTriPairF) and passes the pair on when
+//     A = un'*det' + M >= 0,   B = vn'*det' + M >= 0,   C = det'*(det' - (un' + vn')) + M >= 0
+// (each the single rounding of an exact expression: sign-exact).  With Ed, Eu, Ev the distances
+// between the filter's and the reference's numerators and Dmax >= |det_ref|:
+//     un'*det' >= un*det - (|un| Ed + |det| Eu + Eu Ed) >= -(Dmax (Ed (1+4u) + Eu) + Eu Ed)
+// and likewise for B; for C, |det - un - vn| <= 3 Dmax under the accept hypothesis and the filter's
+// w = det' - (un' + vn') is off by Ew = Ed + Eu + Ev + 2u (|det'| + |un'| + |vn'|):
+//     C' >= -(Dmax (4u Dmax + Ew + 3 Ed) + Ed Ew).
+// Primary rays, 1-norms P12 = |e1||e2|, Pt2 = |tv||e2|, Q = |qv|:  cross products carry 2.01u of
+// their products' magnitudes, an FMA dot product 3.01u, the reference's det / un  10.04u P12 / Pt2:
+// Ed <= 16u P12, Eu <= 16u Pt2, Ev <= 8u Q, Dmax = 1.0001 P12, so every margin above is below
+// 70.1u P12 (P12 + Pt2 + Q); M = 2^-17 P12 (P12 + Pt2 + Q) = 128u P12 (...).
+// Shadow rays (origin o, a = fl(o - g), m = fl(a x L), v0' = fl(v0 - g), R = |a| + |v0'|):
+// Eu <= 22u |e2| R, Ev <= 22u |e1| R (the reference's own 10.04u |tv||e2|, the roundings of a, v0'
+// and m, and the six-term FMA chain), so the margins are below u P12 (70.1 P12 + 24.1 (|e1|+|e2|) R);
+// M = 128u P12 (P12 + (|e1|+|e2|) (|v0'| + rho_max)) covers every ray with |a| <= rho_max, and a
+// ray that starts further out is sent to the exact code for every triangle.
+// ---------------------------------------------------------------------------------------
+struct TriF { // DevTriF as six aligned pairs
+  v2f a, b, c, d, e, pad; // (n1x,n1y) (n1z,n2x) (n2y,n2z) (n3x,n3y) (n3z,M) (-,-)
+};
+
+// 2 triangles x 2 pixels -> A, B, C of each (candidate iff all three >= 0 for a pixel)
+DEVINL void tri2_primary_filter_pk(const TriF (&T)[2], v2f dx, v2f dy, v2f dz, v2f (&A)[2],
+                                   v2f (&B)[2], v2f (&C)[2]) {
+  v2f det0, det1, s0, s1;
+  asm("v_pk_mul_f32 %[det0], %[t0a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[det1], %[t1a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[un0], %[t0b], %[x] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[un1], %[t1b], %[x] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[vn0], %[t0d], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[vn1], %[t1d], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %[det0], %[t0a], %[y], %[det0] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[det1], %[t1a], %[y], %[det1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[un0], %[t0c], %[y], %[un0] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[un1], %[t1c], %[y], %[un1] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[vn0], %[t0d], %[y], %[vn0] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[vn1], %[t1d], %[y], %[vn1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[det0], %[t0b], %[z], %[det0] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[det1], %[t1b], %[z], %[det1] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[un0], %[t0c], %[z], %[un0] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[un1], %[t1c], %[z], %[un1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[vn0], %[t0e], %[z], %[vn0] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %[vn1], %[t1e], %[z], %[vn1] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_add_f32 %[s0], %[un0], %[vn0]\n\t"
+      "v_pk_add_f32 %[s1], %[un1], %[vn1]\n\t"
+      "v_pk_fma_f32 %[un0], %[un0], %[det0], %[t0e] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[un1], %[un1], %[det1], %[t1e] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_add_f32 %[s0], %[det0], %[s0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[s1], %[det1], %[s1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %[vn0], %[vn0], %[det0], %[t0e] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[vn1], %[vn1], %[det1], %[t1e] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[s0], %[det0], %[s0], %[t0e] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[s1], %[det1], %[s1], %[t1e] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t"
+      "s_nop 0"
+      : [un0] "=&v"(A[0]), [un1] "=&v"(A[1]), [vn0] "=&v"(B[0]), [vn1] "=&v"(B[1]), [s0] "=&v"(C[0]),
+        [s1] "=&v"(C[1]), [det0] "=&v"(det0), [det1] "=&v"(det1)
+      : [x] "v"(dx), [y] "v"(dy), [z] "v"(dz), [t0a] "s"(T[0].a), [t0b] "s"(T[0].b),
+        [t0c] "s"(T[0].c), [t0d] "s"(T[0].d), [t0e] "s"(T[0].e), [t1a] "s"(T[1].a),
+        [t1b] "s"(T[1].b), [t1c] "s"(T[1].c), [t1d] "s"(T[1].d), [t1e] "s"(T[1].e));
+  (void)s0;
+  (void)s1;
+}
+
+// sign test of (A, B, C): a pixel is a candidate iff all three are >= 0, i.e. iff the OR of their
+// bit patterns has a clear sign bit (-0 cannot occur: an exact-zero fma result is +0)
+DEVINL int tri_flags(v2f A, v2f B, v2f C, int m) {
+  const int ox = __float_as_int(A.x) | __float_as_int(B.x) | __float_as_int(C.x);
+  const int oy = __float_as_int(A.y) | __float_as_int(B.y) | __float_as_int(C.y);
+  return max3i(m, ox, oy);
+}
+
+// SMEM + 2 pixels per lane: filter over 2 triangles per step, the reference arithmetic
+// (test_tri2_primary on the exact DevTriP records) only for steps with a candidate.  n even.
+template <typename FetchF, typename FetchE>
+DEVINL void closest_tri_primary_filter(FetchF recf, FetchE rece, int n, int base, const V3<v2f> &d,
+                                       Hit (&h)[2]) {
+  auto test2 = [&](const TriF(&T)[2], int k) {
+    v2f A[2], B[2], C[2];
+    tri2_primary_filter_pk(T, d.x, d.y, d.z, A, B, C);
+    const int m = tri_flags(A[1], B[1], C[1], tri_flags(A[0], B[0], C[0], -1));
+    if (ANY_LANE_RARE(m >= 0)) {
+      const V3<v2f> dv[1] = {d};
+      const DevTriP E[2] = {rece(k), rece(k + 1)};
+      test_tri2_primary<v2f, 1>(E, base + k, dv, h);
+    }
+  };
+  if (n >= 2) {
+    TriF A[2], B[2];
+    fetch_batch(recf, 0, A);
+    for (int k = 0; k < n; k += 4) {
+      fetch_batch(recf, recf.landed(A[1].e, min(k + 2, n - 2)), B);
+      test2(A, k);
+      if (k + 2 >= n) break;
+      fetch_batch(recf, recf.landed(B[1].e, min(k + 4, n - 2)), A);
+      test2(B, k + 2);
+    }
+  }
+}
+
+struct TriPairF { // DevTriPairF as sixteen aligned pairs
+  v2f n1x, n1y, n1z, e1x, e1y, e1z, e2x, e2y, e2z, k1x, k1y, k1z, k2x, k2y, k2z, M;
+};
+struct RayTF { // one shadow ray in triangle-filter form: L and m = (o - g) x L as register pairs
+  v2f Lxy;  // (Lx, Ly)
+  v2f Lz_m; // (Lz, mx)
+  v2f myz;  // (my, mz)
+};
+DEVINL RayTF make_ray_tri_filter(f3 o, f3 L, const float (&g)[3], float rho_max, bool &far) {
+  const float ax = o.x - g[0], ay = o.y - g[1], az = o.z - g[2];
+  far = !((fabsf(ax) + fabsf(ay)) + fabsf(az) <= rho_max); // also catches NaN
+  RayTF r;
+  r.Lxy = v2f{L.x, L.y};
+  r.Lz_m = v2f{L.z, ay * L.z - az * L.y};
+  r.myz = v2f{az * L.x - ax * L.z, ax * L.y - ay * L.x};
+  return r;
+}
+
+// 2 pair records (4 triangles) x 1 ray -> A, B, C per record (halves = the record's two triangles)
+DEVINL void tripair2_any_filter_pk(const TriPairF (&R)[2], const RayTF &r, v2f (&A)[2], v2f (&B)[2],
+                                   v2f (&C)[2]) {
+  v2f det0, det1;
+  asm("v_pk_mul_f32 %[det0], %[r0n1x], %[lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[x0], %[r0k2x], %[lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[y0], %[r0k1x], %[lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[det1], %[r1n1x], %[lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[x1], %[r1k2x], %[lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[y1], %[r1k1x], %[lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[det0], %[r0n1y], %[lxy], %[det0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0k2y], %[lxy], %[x0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0k1y], %[lxy], %[y0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[det1], %[r1n1y], %[lxy], %[det1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1k2y], %[lxy], %[x1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1k1y], %[lxy], %[y1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[det0], %[r0n1z], %[lzm], %[det0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0k2z], %[lzm], %[x0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0k1z], %[lzm], %[y0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[det1], %[r1n1z], %[lzm], %[det1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1k2z], %[lzm], %[x1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1k1z], %[lzm], %[y1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      // un = e2.m - L.k2 (into x), vn = L.k1 - e1.m (into y)
+      "v_pk_fma_f32 %[x0], %[r0e2x], %[lzm], %[x0] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0e1x], %[lzm], %[y0] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1e2x], %[lzm], %[x1] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1e1x], %[lzm], %[y1] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0e2y], %[myz], %[x0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0e1y], %[myz], %[y0] op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1e2y], %[myz], %[x1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1e1y], %[myz], %[y1] op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0e2z], %[myz], %[x0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0e1z], %[myz], %[y0] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1e2z], %[myz], %[x1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1e1z], %[myz], %[y1] op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+      "v_pk_add_f32 %[s0], %[x0], %[y0]\n\t"
+      "v_pk_add_f32 %[s1], %[x1], %[y1]\n\t"
+      "v_pk_fma_f32 %[x0], %[x0], %[det0], %[r0M]\n\t"
+      "v_pk_fma_f32 %[x1], %[x1], %[det1], %[r1M]\n\t"
+      "v_pk_add_f32 %[s0], %[det0], %[s0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[s1], %[det1], %[s1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[y0], %[det0], %[r0M]\n\t"
+      "v_pk_fma_f32 %[y1], %[y1], %[det1], %[r1M]\n\t"
+      "v_pk_fma_f32 %[s0], %[det0], %[s0], %[r0M]\n\t"
+      "v_pk_fma_f32 %[s1], %[det1], %[s1], %[r1M]\n\t"
+      "s_nop 0"
+      : [x0] "=&v"(A[0]), [x1] "=&v"(A[1]), [y0] "=&v"(B[0]), [y1] "=&v"(B[1]), [s0] "=&v"(C[0]),
+        [s1] "=&v"(C[1]), [det0] "=&v"(det0), [det1] "=&v"(det1)
+      : [lxy] "v"(r.Lxy), [lzm] "v"(r.Lz_m), [myz] "v"(r.myz), [r0n1x] "s"(R[0].n1x),
+        [r0n1y] "s"(R[0].n1y), [r0n1z] "s"(R[0].n1z), [r0e1x] "s"(R[0].e1x), [r0e1y] "s"(R[0].e1y),
+        [r0e1z] "s"(R[0].e1z), [r0e2x] "s"(R[0].e2x), [r0e2y] "s"(R[0].e2y), [r0e2z] "s"(R[0].e2z),
+        [r0k1x] "s"(R[0].k1x), [r0k1y] "s"(R[0].k1y), [r0k1z] "s"(R[0].k1z), [r0k2x] "s"(R[0].k2x),
+        [r0k2y] "s"(R[0].k2y), [r0k2z] "s"(R[0].k2z), [r0M] "s"(R[0].M), [r1n1x] "s"(R[1].n1x),
+        [r1n1y] "s"(R[1].n1y), [r1n1z] "s"(R[1].n1z), [r1e1x] "s"(R[1].e1x), [r1e1y] "s"(R[1].e1y),
+        [r1e1z] "s"(R[1].e1z), [r1e2x] "s"(R[1].e2x), [r1e2y] "s"(R[1].e2y), [r1e2z] "s"(R[1].e2z),
+        [r1k1x] "s"(R[1].k1x), [r1k1y] "s"(R[1].k1y), [r1k1z] "s"(R[1].k1z), [r1k2x] "s"(R[1].k2x),
+        [r1k2y] "s"(R[1].k2y), [r1k2z] "s"(R[1].k2z), [r1M] "s"(R[1].M));
+}
+
 // ---- any-hit (main.cpp:314-329), general origin -------------------------------------------
 // Per-pixel state of one occlusion() call.  tb is the bound: > 0 while the ray is still
 // looking, set to 0 once it found its FIRST occluder (or if it never looked), so later
@@ -624,6 +807,39 @@ DEVINL void anyhit_tri(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V
       }
     }
     if (m2 < m) test_tri_any<V, NV>(rec(k0 + m2), base + k0 + m2, o, L, a);
+  }
+}
+
+// any-hit over triangles [0, n) of `rece` through the filter (1 ray per lane): 2 pair records
+// (4 triangles) per step; a step in which any lane has a candidate -- or in which a lane's ray
+// starts outside the region the margins were computed for (`far`) -- runs the reference
+// arithmetic (test_tri_any) on the exact records, in index order.  `recf` holds ceil(n/2) pair
+// records; n_first = index of triangle 0 of this range (even).
+constexpr int kTriFilterExit = 64; // triangles between exit checks
+template <typename FetchF, typename FetchE>
+DEVINL void anyhit_tri_filter(FetchF recf, FetchE rece, int n, int base, f3 o, f3 L, const RayTF &rf,
+                              bool far, Any (&a)[1]) {
+  const V3<float> ov[1] = {{o.x, o.y, o.z}}, Lv[1] = {{L.x, L.y, L.z}};
+  const int force = far ? 0 : -1; // a far ray is a candidate for every triangle
+  auto exact = [&](int k, int cnt) {
+    for (int i = 0; i < cnt; ++i) test_tri_any<float, 1>(rece(k + i), base + k + i, ov, Lv, a);
+  };
+  for (int k0 = 0; k0 < n; k0 += kTriFilterExit) {
+    if (!__builtin_amdgcn_ballot_w64(a[0].tb > 0.f)) return;
+    const int m = min(kTriFilterExit, n - k0);
+    const int m4 = m & ~3;
+    for (int k = 0; k < m4; k += 4) {
+      const int r = (k0 + k) >> 1;
+      const TriPairF R[2] = {recf(r), recf(r + 1)};
+      v2f A[2], B[2], C[2];
+      tripair2_any_filter_pk(R, rf, A, B, C);
+      const int f0 = tri_flags(A[0], B[0], C[0], force), f1 = tri_flags(A[1], B[1], C[1], force);
+      if (ANY_LANE_RARE(max(f0, f1) >= 0)) {
+        if (__builtin_amdgcn_ballot_w64(f0 >= 0)) exact(k0 + k, 2);
+        if (__builtin_amdgcn_ballot_w64(f1 >= 0)) exact(k0 + k + 2, 2);
+      }
+    }
+    if (m4 < m) exact(k0 + m4, m - m4);
   }
 }
 

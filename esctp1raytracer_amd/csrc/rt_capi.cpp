@@ -21,8 +21,9 @@ static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNod
               "esc_bvh_node is the public face of esc::BvhNode");
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
-                                  esc::DevSphP *sph_p, esc::DevSphPairP *sph2_p,
-                                  esc::DevSphF *sph_f, hipStream_t stream);
+                                  esc::DevTriF *tri_f, esc::DevSphP *sph_p,
+                                  esc::DevSphPairP *sph2_p, esc::DevSphF *sph_f,
+                                  hipStream_t stream);
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
@@ -66,7 +67,10 @@ struct esc_context {
   esc::DevSphPairP *d_sph2_p = nullptr;
   esc::DevSphF *d_sph_f = nullptr;      // filter forms (rt_brute.h "FILTERS")
   esc::DevSphPairF *d_sph2_f = nullptr;
+  esc::DevTriF *d_tri_f = nullptr;
+  esc::DevTriPairF *d_tri2_f = nullptr;
   float shadow_center[3] = {0, 0, 0};
+  float shadow_rho_max = 0.f;
   int32_t *d_sph_mat = nullptr;
   esc::DevMat *d_mat = nullptr;
   esc::DevLight *d_lights = nullptr;
@@ -314,18 +318,84 @@ int commit(esc_context *ctx, const Staged &s) {
     }
   // filter form of the pair table for shadow rays (rt_brute.h, proof next to pair4_any_filter_pk):
   // centres relative to g = middle of the box of sphere centres, km rounded UP from double
+  // g = middle of the box of everything (sphere centres, triangle corners, light points); rho_max
+  // = twice the 1-norm radius of that box around g: every primary hit point, hence every first
+  // shadow-ray origin, lies inside it; origins further out (quirk S3 can start a later light's ray
+  // beyond the scene) take the exact path
   float g[3] = {0.f, 0.f, 0.f};
-  if (!s.sph.empty()) {
-    float lo[3] = {s.sph[0].cx, s.sph[0].cy, s.sph[0].cz}, hi[3] = {lo[0], lo[1], lo[2]};
-    for (const auto &q : s.sph) {
-      const float c[3] = {q.cx, q.cy, q.cz};
+  double rho = 0.0;
+  {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    auto grow = [&](double x, double y, double z) {
+      const double c[3] = {x, y, z};
       for (int a = 0; a < 3; a++) {
         lo[a] = std::min(lo[a], c[a]);
         hi[a] = std::max(hi[a], c[a]);
       }
+    };
+    for (const auto &q : s.sph) {
+      const double r = std::sqrt(std::max(0.0, (double)q.r2));
+      grow(q.cx - r, q.cy - r, q.cz - r);
+      grow(q.cx + r, q.cy + r, q.cz + r);
     }
-    for (int a = 0; a < 3; a++) g[a] = (float)(0.5 * ((double)lo[a] + (double)hi[a]));
+    for (const auto &t : s.tri) {
+      grow(t.v0[0], t.v0[1], t.v0[2]);
+      grow((double)t.v0[0] + t.e1[0], (double)t.v0[1] + t.e1[1], (double)t.v0[2] + t.e1[2]);
+      grow((double)t.v0[0] + t.e2[0], (double)t.v0[1] + t.e2[1], (double)t.v0[2] + t.e2[2]);
+    }
+    if (lo[0] <= hi[0]) {
+      for (int a = 0; a < 3; a++) {
+        g[a] = (float)(0.5 * (lo[a] + hi[a]));
+        rho += std::max(hi[a] - (double)g[a], (double)g[a] - lo[a]);
+      }
+      rho = 2.0 * rho + 1e-30;
+    }
   }
+  // filter form of the triangle table for shadow rays (rt_brute.h "Triangle FILTERS"), in double,
+  // margins rounded up
+  std::vector<esc::DevTriPairF> tri2f((s.tri.size() + 1) / 2);
+  for (size_t j = 0; j < tri2f.size(); j++)
+    for (int h = 0; h < 2; h++) {
+      esc::DevTriPairF &F = tri2f[j];
+      const size_t k = 2 * j + h;
+      float *f[15] = {&F.n1x[h], &F.n1y[h], &F.n1z[h], &F.e1x[h], &F.e1y[h], &F.e1z[h], &F.e2x[h],
+                      &F.e2y[h], &F.e2z[h], &F.k1x[h], &F.k1y[h], &F.k1z[h], &F.k2x[h], &F.k2y[h],
+                      &F.k2z[h]};
+      if (k >= s.tri.size()) {
+        for (float *x : f) *x = 0.f;
+        F.M[h] = -1.f; // A = 0*0 + M < 0: never a candidate
+        continue;
+      }
+      const esc::DevTri &t = s.tri[k];
+      const float v[3] = {(float)((double)t.v0[0] - g[0]), (float)((double)t.v0[1] - g[1]),
+                          (float)((double)t.v0[2] - g[2])};
+      const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]},
+                   vd[3] = {v[0], v[1], v[2]};
+      auto cross = [](const double *a, const double *b, double *o) {
+        o[0] = a[1] * b[2] - a[2] * b[1];
+        o[1] = a[2] * b[0] - a[0] * b[2];
+        o[2] = a[0] * b[1] - a[1] * b[0];
+      };
+      double n1[3], k1[3], k2[3];
+      cross(e2, e1, n1);
+      cross(e1, vd, k1);
+      cross(e2, vd, k2);
+      for (int a = 0; a < 3; a++) {
+        *f[a] = (float)n1[a];
+        *f[3 + a] = t.e1[a];
+        *f[6 + a] = t.e2[a];
+        *f[9 + a] = (float)k1[a];
+        *f[12 + a] = (float)k2[a];
+      }
+      const double a1 = std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]);
+      const double a2 = std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]);
+      const double av = std::fabs(vd[0]) + std::fabs(vd[1]) + std::fabs(vd[2]);
+      const double p12 = a1 * a2;
+      const double M = 0x1p-17 * p12 * (p12 + (a1 + a2) * (av + rho)) + 0x1p-120;
+      float Mf = (float)M;
+      if ((double)Mf < M) Mf = std::nextafterf(Mf, __builtin_huge_valf());
+      F.M[h] = Mf;
+    }
   std::vector<esc::DevSphPairF> sph2f(sph2.size());
   for (size_t j = 0; j < sph2f.size(); j++)
     for (int h = 0; h < 2; h++) {
@@ -352,7 +422,10 @@ int commit(esc_context *ctx, const Staged &s) {
   int rc;
   if ((rc = upload_vec(ctx->d_sph2_f, sph2f, ctx->stream))) return rc;
   if ((rc = alloc_dev(ctx->d_sph_f, s.sph.size()))) return rc;
+  if ((rc = upload_vec(ctx->d_tri2_f, tri2f, ctx->stream))) return rc;
+  if ((rc = alloc_dev(ctx->d_tri_f, s.tri.size()))) return rc;
   std::memcpy(ctx->shadow_center, g, sizeof(g));
+  ctx->shadow_rho_max = (float)rho;
   if ((rc = upload_vec(ctx->d_tri, s.tri, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_tri_n, s.tri_n, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph, s.sph, ctx->stream))) return rc;
@@ -545,7 +618,8 @@ void esc_context_destroy(esc_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
-                  ctx->d_sph2,   ctx->d_sph2_p, ctx->d_sph_f, ctx->d_sph2_f,
+                  ctx->d_sph2,   ctx->d_sph2_p, ctx->d_sph_f, ctx->d_sph2_f, ctx->d_tri_f,
+                  ctx->d_tri2_f,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits, ctx->d_sq, ctx->d_sq_ctl,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
@@ -857,6 +931,9 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.sph2_p = ctx->d_sph2_p;
   p.sph_f = ctx->d_sph_f;
   p.sph2_f = ctx->d_sph2_f;
+  p.tri_f = ctx->d_tri_f;
+  p.tri2_f = ctx->d_tri2_f;
+  p.shadow_rho_max = ctx->shadow_rho_max;
   std::memcpy(p.shadow_center, ctx->shadow_center, 12);
   {
     static const bool env_off = [] {
@@ -893,8 +970,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   }
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
-    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_sph_p, ctx->d_sph2_p, ctx->d_sph_f,
-                               ctx->stream);
+    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_tri_f, ctx->d_sph_p, ctx->d_sph2_p,
+                               ctx->d_sph_f, ctx->stream);
     if (e) {
       set_error(std::string("k_prepare_primary launch: ") + hipGetErrorString((hipError_t)e));
       return ESC_ERR_HIP;

@@ -73,6 +73,26 @@ struct alignas(16) DevSphPairF {
   float cx[2], cy[2], cz[2], km[2];
 };
 
+// Triangles (rt_brute.h "FILTERS", triangle part).  The reference's numerators are scalar triple
+// products: det = e1.(d x e2) = d.(e2 x e1), u-numerator = tv.(d x e2) = d.(e2 x tv), v-numerator =
+// d.qv, so with the three vectors hoisted a (ray, triangle) pair costs three FMA dot products.
+// primary rays (per frame; tv = camera origin - v0):
+//   n1 = e2 x e1, n2 = e2 x tv, n3 = qv (the exact table's), M = 2^-17 |e1||e2| (|e1||e2| + |tv||e2| + |qv|)
+//   (1-norms), laid out as SGPR pairs: (n1x,n1y) (n1z,n2x) (n2y,n2z) (n3x,n3y) (n3z,M) (pad,pad)
+struct alignas(16) DevTriF {
+  float n1[3], n2[3], n3[3], M, pad[2];
+};
+// shadow rays (per scene): TWO triangles per record, field-interleaved (triangle 2j in the low
+// halves), relative to the scene point g: k1 = e1 x (v0 - g), k2 = e2 x (v0 - g).  With
+// m = (o - g) x L per ray:  u-numerator = e2.m - L.k2,  v-numerator = L.k1 - e1.m,  det = L.n1.
+// M = 2^-17 |e1||e2| (|e1||e2| + (|e1|+|e2|)(|v0-g| + rho_max)), rho_max = RenderParams::shadow_rho_max
+// (rays that start further than rho_max from g take the exact path).  Pad half: all zeros, M = -1
+// (A = -1 < 0: never a candidate).
+struct alignas(16) DevTriPairF {
+  float n1x[2], n1y[2], n1z[2], e1x[2], e1y[2], e1z[2], e2x[2], e2y[2], e2z[2];
+  float k1x[2], k1y[2], k1z[2], k2x[2], k2y[2], k2z[2], M[2];
+};
+
 // scene.h:11-18 Material + whether the owning geometry has normals (main.cpp:733)
 struct alignas(16) DevMat {
   float ka[3];
@@ -254,7 +274,10 @@ struct RenderParams {
   const DevSphPairP *sph2_p; // ceil(n_sph / 2) records
   const DevSphF *sph_f;      // filter form of sph_p (per frame), n_sph records
   const DevSphPairF *sph2_f; // filter form of sph2 (per scene), ceil(n_sph / 2) records
-  float shadow_center[3];    // g of DevSphPairF
+  const DevTriF *tri_f;      // filter form of tri_p (per frame), n_tri records
+  const DevTriPairF *tri2_f; // filter form of tri for shadow rays (per scene), ceil(n_tri / 2)
+  float shadow_rho_max;      // 1-norm radius around g inside which DevTriPairF's margins hold
+  float shadow_center[3];    // g of DevSphPairF / DevTriPairF
   int32_t use_filter;        // 0: every test runs the reference arithmetic (A/B switch, tests)
   const int32_t *sph_mat; // material index of sphere k (already offset by n_geom)
   const DevMat *mat;      // [n_geom + n_sphere_materials]

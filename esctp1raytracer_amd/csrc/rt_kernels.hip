@@ -42,7 +42,8 @@ namespace esc {
 // per-frame constants for primary rays
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, int n_tri,
+k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
+                  DevTriF *__restrict__ tri_f, int n_tri,
                   const DevSph *__restrict__ sph, DevSphP *__restrict__ sph_p,
                   DevSphPairP *__restrict__ sph2_p, DevSphF *__restrict__ sph_f, int n_sph,
                   float ox, float oy, float oz) {
@@ -61,6 +62,21 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, i
     P.tnum = dot(e2, qv);          // :45 numerator
     P.pad[0] = P.pad[1] = P.pad[2] = 0.f;
     tri_p[i] = P;
+    { // filter form (rt_brute.h "Triangle FILTERS"): n1 = e2 x e1, n2 = e2 x tv, n3 = qv
+      const f3 n1 = cross(e2, e1), n2 = cross(e2, tv);
+      const float a1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z);
+      const float a2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
+      const float at = (fabsf(tv.x) + fabsf(tv.y)) + fabsf(tv.z);
+      const float aq = (fabsf(qv.x) + fabsf(qv.y)) + fabsf(qv.z);
+      const float p12 = a1 * a2;
+      DevTriF F;
+      F.n1[0] = n1.x; F.n1[1] = n1.y; F.n1[2] = n1.z;
+      F.n2[0] = n2.x; F.n2[1] = n2.y; F.n2[2] = n2.z;
+      F.n3[0] = qv.x; F.n3[1] = qv.y; F.n3[2] = qv.z;
+      F.M = p12 * ((p12 + at * a2) + aq) * 0x1p-17f + 0x1p-120f;
+      F.pad[0] = F.pad[1] = 0.f;
+      tri_f[i] = F;
+    }
   }
   if (i < n_sph) {
     const DevSph S = sph[i];
@@ -295,7 +311,14 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   V3<V> dv[NV];
   pack3<V, NV>(dir, dv);
   if (STAGE == STAGE_SMEM) {
-    closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dv, hit);
+    if constexpr (PX == 2) {
+      const int n2 = (p.use_filter && p.n_tri >= 8) ? (p.n_tri & ~1) : 0;
+      closest_tri_primary_filter(SmemFetch<TriF>{reinterpret_cast<const TriF *>(p.tri_f)},
+                                 SmemFetch<DevTriP>{p.tri_p}, n2, 0, dv[0], hit);
+      closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p + n2}, p.n_tri - n2, n2, dv, hit);
+    } else {
+      closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dv, hit);
+    }
     if constexpr (PX == 2) {
       // multiples of 8 through the hand-scheduled packed bodies, the tail through the generic one
       const int n8 = p.n_sph & ~7;
@@ -534,7 +557,15 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
             if (in_tris) {
               const V3<V> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
               n_swept += n_here; // upper bound: exits inside a segment are not subtracted
-              anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri + k0}, n_here, k0, sov, sLv, aa);
+              if (p.use_filter && n_here >= 8) { // k0 is even: segment lengths are
+                bool far;
+                const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
+                anyhit_tri_filter(
+                    SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tri2_f) + (k0 >> 1)},
+                    SmemFetch<DevTri>{p.tri + k0}, n_here, k0, so, sL, rt, far, aa);
+              } else {
+                anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri + k0}, n_here, k0, sov, sLv, aa);
+              }
             } else if (p.use_filter) {
               const RayF rf = make_ray_filter(so, sL, p.shadow_center);
               n_swept += 2 * anyhit_sph_pairs_filter(
@@ -739,8 +770,17 @@ __global__ void __launch_bounds__(256) k_anyhit_segment(const RenderParams p, co
         if (HAS_TRI) {
           const V3<float> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
           swept += a.tri_count; // upper bound: exits inside a segment are not subtracted
-          anyhit_tri<float, 1>(SmemFetch<DevTri>{p.tri + a.tri_first}, a.tri_count, a.tri_first, sov,
-                               sLv, aa);
+          if (p.use_filter && a.tri_count >= 8) { // tri_first is even (host: segments are)
+            bool far;
+            const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
+            anyhit_tri_filter(SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tri2_f) +
+                                                  (a.tri_first >> 1)},
+                              SmemFetch<DevTri>{p.tri + a.tri_first}, a.tri_count, a.tri_first, so,
+                              sL, rt, far, aa);
+          } else {
+            anyhit_tri<float, 1>(SmemFetch<DevTri>{p.tri + a.tri_first}, a.tri_count, a.tri_first,
+                                 sov, sLv, aa);
+          }
         }
         if (HAS_SPH) {
           if (p.use_filter) {
@@ -899,12 +939,13 @@ extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t ran
 // host-side launchers (called from rt_capi.cpp)
 // ---------------------------------------------------------------------------------------
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
-                                  esc::DevSphP *sph_p, esc::DevSphPairP *sph2_p,
-                                  esc::DevSphF *sph_f, hipStream_t stream) {
+                                  esc::DevTriF *tri_f, esc::DevSphP *sph_p,
+                                  esc::DevSphPairP *sph2_p, esc::DevSphF *sph_f,
+                                  hipStream_t stream) {
   const int n = p->n_tri > p->n_sph ? p->n_tri : p->n_sph;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
-                     tri_p, p->n_tri, p->sph, sph_p, sph2_p, sph_f, p->n_sph, p->origin[0],
+                     tri_p, tri_f, p->n_tri, p->sph, sph_p, sph2_p, sph_f, p->n_sph, p->origin[0],
                      p->origin[1], p->origin[2]);
   return (int)hipGetLastError();
 }

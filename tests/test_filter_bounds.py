@@ -133,3 +133,142 @@ def test_filter_margins_match_the_documented_budget():
     assert 32 * U == 2.0 ** -19 and 256 * U == 2.0 ** -16
     assert 32 > 13.3 + 1 + 5 * 32 * U          # primary: 13.3u + rounding of ccm + of A2f
     assert 251 > 99.4 + 4.01 and 255 > 99.4     # shadow: ray side (nko), sphere side (km)
+
+
+# ------------------------------------------------------------------ triangles
+def ref_cross(ax, ay, az, bx, by, bz):  # vec.h:103, no fusion
+    return (f32(f32(ay * bz) - f32(az * by)), f32(f32(az * bx) - f32(ax * bz)),
+            f32(f32(ax * by) - f32(ay * bx)))
+
+
+def l1(x, y, z):
+    return f32(f32(np.abs(x) + np.abs(y)) + np.abs(z))
+
+
+def fdot(ax, ay, az, bx, by, bz):  # mul, fma, fma
+    return fma(az, bz, fma(ay, by, f32(ax * bx)))
+
+
+def uv_accept(det, un, vn):
+    """ray_triangle.h:21-41 on the fp32 numerators: every reject that involves det, u, v (the t
+    rejects only shrink the accepted set, so passing these is implied by an accept)"""
+    eps = np.float64(np.finfo(np.float32).eps)
+    d = det.astype(np.float64)
+    ok = ~((d > -eps) & (d < eps))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        u2 = (un.astype(np.float64) * inv).astype(f32)
+        v2 = (vn.astype(np.float64) * inv).astype(f32)
+    ok &= ~((u2 < f32(eps)) | (u2 > f32(1)))
+    ok &= ~((v2 < f32(eps)) | (f32(u2 + v2) > f32(1)))
+    return ok
+
+
+def rays_near_edges(rng, o, v0, e1, e2, n):
+    """directions from o to points of the triangle's plane whose barycentrics hug the boundary
+    (u, v or 1-u-v within 1e-7..1e-2 of 0, either side), so hits and misses are a hair apart"""
+    u = rng.uniform(0, 1, n)
+    v = rng.uniform(0, 1, n) * (1 - u)
+    which = rng.integers(0, 3, n)
+    delta = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-7, -2, n)
+    u = np.where(which == 0, delta, u)
+    v = np.where(which == 1, delta, v)
+    v = np.where(which == 2, 1 - u + delta, v)
+    p = v0.astype(np.float64) + u[:, None] * e1.astype(np.float64) + v[:, None] * e2.astype(np.float64)
+    return unit(p - o.astype(np.float64))
+
+
+@pytest.mark.parametrize("scale,size", [(1.0, 1.0), (30.0, 0.1), (30.0, 30.0), (1000.0, 0.01)])
+def test_triangle_primary_filter_never_rejects_a_reference_candidate(scale, size):
+    """k_prepare_primary's DevTriF + tri2_primary_filter_pk vs ray_triangle.h's numerators with
+    edges, tvec and qvec hoisted (all rays leave one origin per triangle here)."""
+    rng = np.random.default_rng(int(scale * 10 + size * 100))
+    n = 1_000_000
+    o = (rng.uniform(-1, 1, (n, 3)) * scale).astype(f32)
+    v0 = (rng.uniform(-1, 1, (n, 3)) * scale).astype(f32)
+    e1 = (rng.normal(size=(n, 3)) * size).astype(f32)
+    e2 = (rng.normal(size=(n, 3)) * size).astype(f32)
+    d = rays_near_edges(rng, o, v0, e1, e2, n)
+    dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+    tv = [f32(o[:, i] - v0[:, i]) for i in range(3)]
+    qv = ref_cross(*tv, e1[:, 0], e1[:, 1], e1[:, 2])                     # ray_triangle.h:37
+    # reference numerators (ray_triangle.h:18,21,32,40)
+    pv = ref_cross(dx, dy, dz, e2[:, 0], e2[:, 1], e2[:, 2])
+    det = ref_dot(e1[:, 0], e1[:, 1], e1[:, 2], *pv)
+    un = ref_dot(*tv, *pv)
+    vn = ref_dot(*qv, dx, dy, dz)
+    ref_ok = uv_accept(det, un, vn)
+    # filter record (k_prepare_primary) and evaluation (tri2_primary_filter_pk)
+    n1 = ref_cross(e2[:, 0], e2[:, 1], e2[:, 2], e1[:, 0], e1[:, 1], e1[:, 2])
+    n2 = ref_cross(e2[:, 0], e2[:, 1], e2[:, 2], *tv)
+    a1, a2, at, aq = l1(*e1.T), l1(*e2.T), l1(*tv), l1(*qv)
+    p12 = f32(a1 * a2)
+    M = f32(f32(f32(p12 * f32(f32(p12 + f32(at * a2)) + aq)) * f32(2.0 ** -17)) + f32(2.0 ** -120))
+    detf, unf, vnf = fdot(*n1, dx, dy, dz), fdot(*n2, dx, dy, dz), fdot(*qv, dx, dy, dz)
+    s = f32(unf + vnf)
+    A, B = fma(unf, detf, M), fma(vnf, detf, M)
+    C = fma(detf, f32(detf - s), M)
+    filt_ok = (A >= 0) & (B >= 0) & (C >= 0)
+    assert ref_ok.sum() > n // 8 and (~ref_ok).sum() > n // 8
+    missed = ref_ok & ~filt_ok
+    assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the filter"
+    dr = unit(rng.normal(size=(n, 3)))  # and it filters: random directions mostly fail
+    detf, unf, vnf = fdot(*n1, *dr.T), fdot(*n2, *dr.T), fdot(*qv, *dr.T)
+    ok = (fma(unf, detf, M) >= 0) & (fma(vnf, detf, M) >= 0) & \
+         (fma(detf, f32(detf - f32(unf + vnf)), M) >= 0)
+    assert ok.mean() < 0.5
+
+
+@pytest.mark.parametrize("scale,size,offset", [(1.0, 1.0, 0.0), (30.0, 0.1, 0.0), (30.0, 5.0, 800.0),
+                                               (1000.0, 0.01, 0.0)])
+def test_triangle_shadow_filter_never_rejects_a_reference_candidate(scale, size, offset):
+    """commit()'s DevTriPairF + make_ray_tri_filter + tripair2_any_filter_pk vs ray_triangle.h's
+    numerators for arbitrary origins (test_tri_any), rays inside rho_max."""
+    rng = np.random.default_rng(int(scale + size * 10 + offset))
+    n = 1_000_000
+    o = (rng.uniform(-1, 1, (n, 3)) * scale + offset).astype(f32)
+    v0 = (rng.uniform(-1, 1, (n, 3)) * scale + offset).astype(f32)
+    e1 = (rng.normal(size=(n, 3)) * size).astype(f32)
+    e2 = (rng.normal(size=(n, 3)) * size).astype(f32)
+    L = rays_near_edges(rng, o, v0, e1, e2, n)
+    Lx, Ly, Lz = L[:, 0], L[:, 1], L[:, 2]
+    # reference numerators (test_tri_any order)
+    pv = ref_cross(Lx, Ly, Lz, e2[:, 0], e2[:, 1], e2[:, 2])
+    det = ref_dot(e1[:, 0], e1[:, 1], e1[:, 2], *pv)
+    tv = [f32(o[:, i] - v0[:, i]) for i in range(3)]
+    un = ref_dot(*tv, *pv)
+    qv = ref_cross(*tv, e1[:, 0], e1[:, 1], e1[:, 2])
+    vn = ref_dot(Lx, Ly, Lz, *qv)
+    ref_ok = uv_accept(det, un, vn)
+    # host side (commit()): g, rho_max, record in double -> fp32, M rounded up
+    pts = np.concatenate([v0, v0 + e1, v0 + e2]).astype(np.float64)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    g = (0.5 * (lo + hi)).astype(f32)
+    rho = 2.0 * np.maximum(hi - g, g - lo).sum() + 1e-30
+    vd = (v0.astype(np.float64) - g).astype(f32).astype(np.float64)
+    e1d, e2d = e1.astype(np.float64), e2.astype(np.float64)
+    n1 = np.cross(e2d, e1d).astype(f32)
+    k1 = np.cross(e1d, vd).astype(f32)
+    k2 = np.cross(e2d, vd).astype(f32)
+    a1, a2, av = np.abs(e1d).sum(1), np.abs(e2d).sum(1), np.abs(vd).sum(1)
+    p12 = a1 * a2
+    Md = 2.0 ** -17 * p12 * (p12 + (a1 + a2) * (av + rho)) + 2.0 ** -120
+    M = Md.astype(f32)
+    low = M.astype(np.float64) < Md
+    M[low] = np.nextafter(M[low], f32(np.inf))
+    # device side: a = o - g, m = a x L (un-fused), then the FMA chains
+    a = [f32(o[:, i] - g[i]) for i in range(3)]
+    assert float((np.abs(a[0]) + np.abs(a[1]) + np.abs(a[2])).max()) <= rho  # not `far`
+    m = ref_cross(*a, Lx, Ly, Lz)
+    detf = fdot(*n1.T, Lx, Ly, Lz)
+    x = fdot(*k2.T, Lx, Ly, Lz)
+    y = fdot(*k1.T, Lx, Ly, Lz)
+    unf = fma(e2[:, 2], m[2], fma(e2[:, 1], m[1], fma(e2[:, 0], m[0], -x)))
+    vnf = fma(-e1[:, 2], m[2], fma(-e1[:, 1], m[1], fma(-e1[:, 0], m[0], y)))
+    s = f32(unf + vnf)
+    A, B = fma(unf, detf, M), fma(vnf, detf, M)
+    C = fma(detf, f32(detf - s), M)
+    filt_ok = (A >= 0) & (B >= 0) & (C >= 0)
+    assert ref_ok.sum() > n // 8 and (~ref_ok).sum() > n // 8
+    missed = ref_ok & ~filt_ok
+    assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the filter"
