@@ -812,9 +812,9 @@ int render_shade_queue(esc_context *ctx, esc::RenderParams &p, int px, hipEvent_
   const size_t qcap = (npx + 63) / 64 * 64 + 64 * 4096; // ids per queue: every pixel + one partly
                                                          // filled chunk per workgroup
   const bool multi = p.n_lights > 1;
-  // one allocation: rays | normals | q0 | q1 | state
-  const size_t off_rays = 0, off_nrm = off_rays + npx * sizeof(esc::ShadowRay),
-               off_q0 = off_nrm + npx * sizeof(esc::ShadeNormal), off_q1 = off_q0 + qcap * 4,
+  // one allocation: rays | q0 | q1 | state
+  const size_t off_rays = 0, off_q0 = off_rays + npx * sizeof(esc::ShadowRay),
+               off_q1 = off_q0 + qcap * 4,
                off_state = off_q1 + qcap * 4, total = off_state + (multi ? npx * 16 : 0);
   if (ctx->sq_pixels < npx || (multi && ctx->sq_lights < 2)) {
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // an earlier frame may still use the old scratch
@@ -833,7 +833,6 @@ int render_shade_queue(esc_context *ctx, esc::RenderParams &p, int px, hipEvent_
   char *base = (char *)ctx->d_sq;
   // offsets are computed for THIS band (<= the allocation: the layout only shrinks with npx)
   p.sq.rays = (esc::ShadowRay *)(base + off_rays);
-  p.sq.nrm = (esc::ShadeNormal *)(base + off_nrm);
   p.sq.q[0] = (uint32_t *)(base + off_q0);
   p.sq.q[1] = (uint32_t *)(base + off_q1);
   p.sq.state = multi ? (float *)(base + off_state) : nullptr;

@@ -150,14 +150,9 @@ struct alignas(16) ShadowRay { // one per pixel of the band, indexed by band-loc
   float lx, ly, lz; // unit direction (main.cpp:766)
   int32_t kocc;     // -1, or the first occluder's index in (triangles, spheres) order
 };
-struct alignas(16) ShadeNormal { // main.cpp:723-738 result, kept from setup to finish
-  float nx, ny, nz;
-  int32_t mi; // material index
-};
 constexpr uint32_t kQueueInvalid = 0xffffffffu; // pad entry of a partly filled 64-id chunk
 struct ShadeQueue {
   ShadowRay *rays;    // [n_pixels]
-  ShadeNormal *nrm;   // [n_pixels]
   uint32_t *q[2];     // ping-pong queues of pixel ids, in chunks of 64
   uint32_t *ctl;      // per (light, segment): [0] chunks appended to the segment's OUTPUT queue,
                       // [1] work-fetch cursor; zeroed at the start of every frame

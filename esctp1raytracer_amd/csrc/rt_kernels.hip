@@ -173,9 +173,14 @@ template <int PX> struct Tile {
   DEVINL Tile(const RenderParams &p) {
     constexpr int TW = 32 * PX;
     const int tiles_x = (p.W + TW - 1) / TW;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int tid = threadIdx.x;
-    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    init(p, blockIdx.x % tiles_x, blockIdx.x / tiles_x, threadIdx.x);
+    wave = __builtin_amdgcn_readfirstlane(wave); // wave-uniform for the workgroup's own thread id
+  }
+  // tile (tx, ty) of the band as seen by thread `tid` of a 256-thread workgroup
+  DEVINL Tile(const RenderParams &p, int tx, int ty, int tid) { init(p, tx, ty, tid); }
+  DEVINL void init(const RenderParams &p, int tx, int ty, int tid) {
+    constexpr int TW = 32 * PX;
+    wave = tid >> 6; // `tid` may be another thread's id (per lane): no readfirstlane here
     lane = tid & 63;
     lx0 = (wave & 1) * (16 * PX) + (lane & 15);
     ly = ((wave >> 1) << 2) + (lane >> 4);
@@ -670,31 +675,6 @@ __global__ void __launch_bounds__(256) k_shadow_setup(const RenderParams p, int 
   if (idx < 0) return; // no record for a miss: the first segment reads the idx plane itself
   const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
   float t = (MULTI && li > 0) ? p.sq.state[px] : p.hits.t[px];
-  if (li == 0) { // main.cpp:723-738, once per pixel (per-lane gathers)
-    f3 N;
-    int mi;
-    if (idx < p.n_tri) {
-      const DevTri Tr = p.tri[idx];
-      N = normalize(cross(ld3(Tr.e1), ld3(Tr.e2))); // :728-731
-      mi = Tr.geom;
-      if (p.mat[mi].has_normals) { // :733-738 with u == 0 (quirk S1)
-        const DevTriN Q = p.tri_n[idx];
-        const float u = 0.f, v = p.hits.v[px];
-        N = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
-      }
-    } else {
-      const int k = idx - p.n_tri;
-      const DevSph S = p.sph[k];
-      N = normalize((origin + primary_dir(p, w, h) * t) - mk(S.cx, S.cy, S.cz)); // extension
-      mi = p.sph_mat[k];
-    }
-    ShadeNormal nm;
-    nm.nx = N.x;
-    nm.ny = N.y;
-    nm.nz = N.z;
-    nm.mi = mi;
-    p.sq.nrm[px] = nm;
-  }
   const DevLight Lt = p.lights[li];
   const uint32_t face = (p.face_mode == 0) ? (uint32_t)p.fixed_face
                         : (Lt.n_faces == 1) ? 0u
@@ -864,12 +844,31 @@ __global__ void __launch_bounds__(256) k_shade_finish(const RenderParams p, int 
     if (R.kocc >= 0) {
       if (MULTI) p.sq.state[px] = R.ox; // occlusion() wrote the occluder's t2 into t (quirk S3)
     } else {                            // :772-773 `continue` otherwise
-      const ShadeNormal nm = p.sq.nrm[px];
-      const f3 N = mk(nm.nx, nm.ny, nm.nz), rL = mk(R.lx, R.ly, R.lz);
+      // main.cpp:723-738 normal of the hit (per-lane gathers; only unoccluded pixels get here)
+      const int32_t idx = p.hits.idx[px];
+      f3 N;
+      int mi;
+      if (idx < p.n_tri) {
+        const DevTri Tr = p.tri[idx];
+        N = normalize(cross(ld3(Tr.e1), ld3(Tr.e2))); // :728-731
+        mi = Tr.geom;
+        if (p.mat[mi].has_normals) { // :733-738 with u == 0 (quirk S1)
+          const DevTriN Q = p.tri_n[idx];
+          const float u = 0.f, v = p.hits.v[px];
+          N = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
+        }
+      } else {
+        const int k = idx - p.n_tri;
+        const DevSph S = p.sph[k];
+        const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
+        N = normalize((origin + primary_dir(p, w, h) * p.hits.t[px]) - mk(S.cx, S.cy, S.cz));
+        mi = p.sph_mat[k];
+      }
+      const f3 rL = mk(R.lx, R.ly, R.lz);
       const float nl = (float)p.n_lights;
       const float d = dot(N, rL); // :775
       if (!(d <= 0.f)) {          // :777
-        const DevMat M = p.mat[nm.mi];                // :768
+        const DevMat M = p.mat[mi];                   // :768
         f3 c = ld3(M.ka) * 0.5f + ld3(M.ke);          // :769-770
         if (nl != 1.f) c = c / nl;                    // x / 1.0f == x bit for bit
         const f3 Hh = normalize((N + rL) * 2.f);      // :780

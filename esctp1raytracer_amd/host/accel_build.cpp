@@ -87,6 +87,22 @@ OriginBounds origin_bounds(const std::vector<DevTri> &tri, const std::vector<Dev
   double diag = 0;
   for (int a = 0; a < 3; a++) diag += (ob.hi[a] - ob.lo[a]) * (ob.hi[a] - ob.lo[a]);
   diag = std::sqrt(diag);
+  if (light_points_xyz0.size() > 4) {
+    // More than one light point: quirk S3 starts the NEXT light's shadow ray at
+    // camera + dir * (t_occ - eps), t_occ = the previous light's occluder distance along ITS shadow
+    // ray (main.cpp:757 with the t occlusion() left behind) -- a point on the primary ray that can
+    // lie past the hit surface and outside the scene box.  t_occ < that shadow ray's length <= the
+    // diagonal of (scene + lights + camera), so every such origin is within `diag` of the camera.
+    ob.ball = diag;
+    for (int a = 0; a < 3; a++) ob.cam[a] = origin[a];
+    for (int a = 0; a < 3; a++) {
+      ob.lo[a] = std::min(ob.lo[a], (double)origin[a] - diag);
+      ob.hi[a] = std::max(ob.hi[a], (double)origin[a] + diag);
+    }
+    diag = 0;
+    for (int a = 0; a < 3; a++) diag += (ob.hi[a] - ob.lo[a]) * (ob.hi[a] - ob.lo[a]);
+    diag = std::sqrt(diag);
+  }
   const double g = 0.1 * diag + 1e-6;
   for (int a = 0; a < 3; a++) {
     ob.lo[a] -= g;

@@ -15,12 +15,24 @@ struct PrimBox {
 };
 
 // where ray origins can be: the camera and every surface point of the scene (shadow rays start
-// on the surface that was hit, main.cpp:757-758)
+// on the surface that was hit, main.cpp:757-758) and, with more than one light point, a ball of
+// radius `ball` around the camera (quirk S3: a later light's shadow ray starts on the primary ray
+// at the previous occluder's distance, possibly outside the scene)
 struct OriginBounds {
   double lo[3], hi[3];
+  double ball = 0.0;
+  double cam[3] = {0, 0, 0}; // the camera the bounds were built for
+  // may a frame with the camera at p use pads computed for these bounds?  (a camera that moved by
+  // d sees a scene diagonal at most d longer, so its ball is at most ball + d)
   bool contains(const float p[3]) const {
+    double r = 0.0;
+    if (ball > 0.0) {
+      double d2 = 0.0;
+      for (int a = 0; a < 3; a++) d2 += ((double)p[a] - cam[a]) * ((double)p[a] - cam[a]);
+      r = ball + __builtin_sqrt(d2);
+    }
     for (int a = 0; a < 3; a++)
-      if (!(p[a] >= lo[a] && p[a] <= hi[a])) return false;
+      if (!(p[a] - r >= lo[a] && p[a] + r <= hi[a])) return false;
     return true;
   }
 };

@@ -668,6 +668,38 @@ def test_bvh_two_lights_first_occluder_in_order(esc, renderer):
                         face_mode=esc.ESC_FACE_FIXED, fixed_face=1)
 
 
+def test_bvh_second_light_origin_outside_the_scene_box(esc, renderer):
+    """Quirk S3 with two lights: light 2's shadow ray starts at camera + dir * (t_occ - eps), where
+    t_occ is light 1's occluder distance ALONG ITS SHADOW RAY.  With light 1 far away and its
+    occluder next to it, t_occ is several times the primary hit distance: the origin lies far
+    past the floor, outside the box of the scene.  The box pads of the tree must hold there too
+    (OriginBounds now includes a camera-centred ball when there is more than one light
+    point).  Spheres sit under the floor, where those origins land, on the way to light 2."""
+    rng = np.random.default_rng(21)
+    floor = np.array([[-6, 0, 4], [6, 0, 4], [6, 0, -6], [-6, 0, 4], [6, 0, -6], [-6, 0, -6]], np.float32)
+    lA = np.array([[-0.5, 30, -40], [0.5, 30, -40], [0, 30, -41]], np.float32)   # far away
+    lB = np.array([[8, -3, 2], [8.4, -3, 2], [8, -2.6, 2.2]], np.float32)          # below the floor level
+    geoms = [{"vertex": floor, "face_index": np.arange(6).reshape(2, 3), "material": ol.WHITE},
+             {"vertex": lA, "face_index": np.array([[0, 1, 2]]), "material": ol.LIGHT_A},
+             {"vertex": lB, "face_index": np.array([[0, 1, 2]]), "material": ol.LIGHT_B}]
+    big = np.array([[0.0, 26.0, -35.0, 6.0]])  # hides light A from most of the floor, next to it
+    n = 150
+    under = np.concatenate([rng.uniform(-8, 8, (n, 1)), rng.uniform(-30, -1, (n, 1)),
+                            rng.uniform(-45, 3, (n, 1)), rng.uniform(0.2, 1.5, (n, 1))], axis=1)
+    sph = np.concatenate([big, under]).astype(np.float32)
+    mats = np.stack([ol.material13(ka=m, kd=m) for m in rng.uniform(0.2, 0.9, (len(sph), 3))])
+    d = ol.scene_dict(geoms, sph, mats)
+    assert len(d["light_sources"]) == 2
+    eye, look = (0.0, 1.0, 3.0), (0.0, 0.0, 0.0)
+    W, H = 224, 128
+    ref, rc = ol.oracle_render(d, eye, look, W, H, threads=8, return_counters=True)
+    assert rc["hit_pixels"] > W * H // 4
+    for stage in (esc.ESC_STAGE_AUTO, esc.ESC_STAGE_BVH):
+        gpu, u8, _ = render_both(esc, renderer, d, eye, look, W, H, stage=stage)
+        assert_bit_equal(gpu, ref, f"S3 far origin/stage{stage}")
+    assert ref.sum() > 0
+
+
 @pytest.mark.parametrize("W,H", [(33, 9), (97, 61), (2, 2), (31, 7)])
 def test_bvh_ragged_sizes(esc, renderer, W, H):
     d = ol.load_dump("one")
