@@ -114,9 +114,6 @@ DEVINL void closest_tri_primary(Fetch rec, int n, int base, const V3<V> (&d)[NV]
 struct SphP2 { // DevSphP seen as two aligned pairs: (ocx, ocy), (ocz, cc)
   v2f xy, zc;
 };
-struct Sph2 { // DevSph: (cx, cy), (cz, r2)
-  v2f xy, zr;
-};
 
 DEVINL int max3i(int a, int b, int c) { return max(max(a, b), c); }
 DEVINL bool any_nonneg(v2f a, v2f b, v2f c, v2f d) {
@@ -165,97 +162,15 @@ DEVINL void sph4_primary_pk(const SphP2 (&s)[4], v2f dx, v2f dy, v2f dz, v2f (&b
         [s3a] "s"(s[3].xy), [s3b] "s"(s[3].zc));
 }
 
-// shadow rays, 2 spheres x 2 pixels:
-//   oc = o - c ; b = (ocx*Lx + ocy*Ly) + ocz*Lz ; cc = ((ocx*ocx + ocy*ocy) + ocz*ocz) - r2 ;
-//   q = b*b - cc
-DEVINL void sph2_any_pk(const Sph2 (&s)[2], v2f ox, v2f oy, v2f oz, v2f Lx, v2f Ly, v2f Lz,
-                        v2f (&b)[2], v2f (&q)[2]) {
-  v2f ax, ay, az, bx, by, bz, t0, t1; // oc of sphere A / B, temporaries
-  asm("v_pk_add_f32 %[ax], %[ox], %[sAxy] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[bx], %[ox], %[sBxy] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[ay], %[oy], %[sAxy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[by], %[oy], %[sBxy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[az], %[oz], %[sAzr] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[bz], %[oz], %[sBzr] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      // b = dot(oc, L)
-      "v_pk_mul_f32 %[bA], %[ax], %[Lx]\n\t"
-      "v_pk_mul_f32 %[bB], %[bx], %[Lx]\n\t"
-      "v_pk_mul_f32 %[t0], %[ay], %[Ly]\n\t"
-      "v_pk_mul_f32 %[t1], %[by], %[Ly]\n\t"
-      "v_pk_add_f32 %[bA], %[bA], %[t0]\n\t"
-      "v_pk_add_f32 %[bB], %[bB], %[t1]\n\t"
-      "v_pk_mul_f32 %[t0], %[az], %[Lz]\n\t"
-      "v_pk_mul_f32 %[t1], %[bz], %[Lz]\n\t"
-      "v_pk_add_f32 %[bA], %[bA], %[t0]\n\t"
-      "v_pk_add_f32 %[bB], %[bB], %[t1]\n\t"
-      // dot(oc, oc)
-      "v_pk_mul_f32 %[qA], %[ax], %[ax]\n\t"
-      "v_pk_mul_f32 %[qB], %[bx], %[bx]\n\t"
-      "v_pk_mul_f32 %[t0], %[ay], %[ay]\n\t"
-      "v_pk_mul_f32 %[t1], %[by], %[by]\n\t"
-      "v_pk_add_f32 %[qA], %[qA], %[t0]\n\t"
-      "v_pk_add_f32 %[qB], %[qB], %[t1]\n\t"
-      "v_pk_mul_f32 %[t0], %[az], %[az]\n\t"
-      "v_pk_mul_f32 %[t1], %[bz], %[bz]\n\t"
-      "v_pk_add_f32 %[qA], %[qA], %[t0]\n\t"
-      "v_pk_add_f32 %[qB], %[qB], %[t1]\n\t"
-      // cc = dot - r2
-      "v_pk_add_f32 %[qA], %[qA], %[sAzr] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[qB], %[qB], %[sBzr] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      // q = b*b - cc
-      "v_pk_mul_f32 %[t0], %[bA], %[bA]\n\t"
-      "v_pk_mul_f32 %[t1], %[bB], %[bB]\n\t"
-      "v_pk_add_f32 %[qA], %[t0], %[qA] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[qB], %[t1], %[qB] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "s_nop 0"
-      : [bA] "=&v"(b[0]), [bB] "=&v"(b[1]), [qA] "=&v"(q[0]), [qB] "=&v"(q[1]), [ax] "=&v"(ax),
-        [ay] "=&v"(ay), [az] "=&v"(az), [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz),
-        [t0] "=&v"(t0), [t1] "=&v"(t1)
-      : [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [Lx] "v"(Lx), [Ly] "v"(Ly), [Lz] "v"(Lz),
-        [sAxy] "s"(s[0].xy), [sAzr] "s"(s[0].zr), [sBxy] "s"(s[1].xy), [sBzr] "s"(s[1].zr));
-}
-
-// ---- 1 pixel per lane, TWO SPHERES per packed op -------------------------------------------
-// Same idea with the roles swapped: the lane keeps one ray and the two halves of every v_pk op
-// hold spheres 2j and 2j+1, whose constants arrive pair-interleaved (DevSphPairP) and feed the
-// ops as plain SGPR pairs; the ray's components are broadcast to both halves through op_sel.
-// Measured on c4: primary pass 11.4 -> 10.4 ms.  The 32-op shadow body gains nothing by itself
-// (13.1 vs 12.6 ms scalar: its v_pk ops run at ~8 cycles instead of ~4, the register pairs hipcc
-// hands to an opaque asm collide in the VGPR banks), but it must be packed too: with a packed
-// primary pass and a SCALAR shadow pass sharing the SIMDs the frame took 30.9 ms (rocprofv3:
-// fewer VALU instructions, +48 % issue stalls), against 23.5 ms packed/packed and 24.0 ms
-// scalar/scalar.
-struct PairP { // DevSphPairP as four aligned pairs
-  v2f x, y, z, c;
-};
+// ---- 1 ray per lane, TWO SPHERES per packed op (shadow rays) ---------------------------------
+// The lane keeps one ray and the two halves of every v_pk op hold spheres 2j and 2j+1, whose
+// constants arrive pair-interleaved (DevSphPair) and feed the ops as plain SGPR pairs; the ray's
+// components are broadcast to both halves through op_sel.  This is the REFERENCE arithmetic of
+// the shadow test (16 operations per pair, no fusion): what the filter's candidates run, and what
+// every pair runs under ESC_RENDER_EXACT_ONLY.
 struct PairG { // DevSphPair
   v2f x, y, z, r;
 };
-
-// primary: b = (ocx*dx + ocy*dy) + ocz*dz ; q = b*b - cc, for records R0 (spheres 0,1), R1 (2,3)
-DEVINL void pair2_primary_pk(const PairP (&R)[2], v2f dxy, v2f dz_, v2f (&b)[2], v2f (&q)[2]) {
-  v2f t0, t1;
-  asm("v_pk_mul_f32 %[b0], %[r0x], %[dxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[b1], %[r1x], %[dxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t0], %[r0y], %[dxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %[t1], %[r1y], %[dxy] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
-      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
-      "v_pk_mul_f32 %[t0], %[r0z], %[dz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %[t1], %[r1z], %[dz] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-      "v_pk_add_f32 %[b0], %[b0], %[t0]\n\t"
-      "v_pk_add_f32 %[b1], %[b1], %[t1]\n\t"
-      "v_pk_mul_f32 %[q0], %[b0], %[b0]\n\t"
-      "v_pk_mul_f32 %[q1], %[b1], %[b1]\n\t"
-      "v_pk_add_f32 %[q0], %[q0], %[r0c] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_pk_add_f32 %[q1], %[q1], %[r1c] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "s_nop 0"
-      : [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [q0] "=&v"(q[0]), [q1] "=&v"(q[1]), [t0] "=&v"(t0),
-        [t1] "=&v"(t1)
-      : [dxy] "v"(dxy), [dz] "v"(dz_), [r0x] "s"(R[0].x), [r0y] "s"(R[0].y), [r0z] "s"(R[0].z),
-        [r0c] "s"(R[0].c), [r1x] "s"(R[1].x), [r1y] "s"(R[1].y), [r1z] "s"(R[1].z),
-        [r1c] "s"(R[1].c));
-}
 
 // shadow: oc = o - c ; b = (ocx*Lx + ocy*Ly) + ocz*Lz ; cc = ((ocx^2 + ocy^2) + ocz^2) - r2 ;
 // q = b*b - cc, for records R0 (spheres 0,1) and R1 (spheres 2,3)
@@ -306,54 +221,6 @@ DEVINL void pair2_any_pk(const PairG (&R)[2], v2f oxy, v2f oz_, v2f Lxy, v2f Lz_
       : [oxy] "v"(oxy), [oz] "v"(oz_), [Lxy] "v"(Lxy), [Lz] "v"(Lz_), [r0x] "s"(R[0].x),
         [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0r] "s"(R[0].r), [r1x] "s"(R[1].x),
         [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1r] "s"(R[1].r));
-}
-
-// closest hit over pair records [0, n_rec): each record = spheres base+2j, base+2j+1
-template <typename Fetch>
-DEVINL void closest_sph_primary_pairs(Fetch rec, int n_rec, int base, f3 d, Hit &h) {
-  const v2f dxy = {d.x, d.y}, dz_ = {d.z, 0.f};
-  auto test = [&](const PairP(&R)[2], int idx) {
-    v2f b[2], q[2];
-    pair2_primary_pk(R, dxy, dz_, b, q);
-    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
-                      __float_as_int(q[1].y));
-    if (ANY_LANE_RARE(m >= 0)) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { // index order: record i, half c
-          float t2;
-          if (sph_exact(comp(b[i], c), comp(q[i], c), h.t, t2)) {
-            h.t = t2;
-            h.idx = idx + 2 * i + c;
-          }
-        }
-    }
-  };
-  const int n4 = n_rec & ~3;
-  if (n4) {
-    PairP A[2], B[2];
-    fetch_batch(rec, 0, A);
-    for (int k = 0; k < n4; k += 4) {
-      fetch_batch(rec, rec.landed(A[1].c, k + 2), B);
-      test(A, base + 2 * k);
-      fetch_batch(rec, rec.landed(B[1].c, min(k + 4, n_rec - 2)), A);
-      test(B, base + 2 * k + 4);
-    }
-  }
-  for (int k = n4; k < n_rec; ++k) { // < 4 records left: pair each with itself (idempotent)
-    const PairP R[2] = {rec(k), rec(k)};
-    v2f b[2], q[2];
-    pair2_primary_pk(R, dxy, dz_, b, q);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      float t2;
-      if (sph_exact(comp(b[0], c), comp(q[0], c), h.t, t2)) {
-        h.t = t2;
-        h.idx = base + 2 * k + c;
-      }
-    }
-  }
 }
 
 // ---- closest hit, primary rays, spheres ---------------------------------------------------
@@ -900,44 +767,6 @@ DEVINL void anyhit_sph(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V
     for (int k = mb; k < m; ++k) {
       const DevSph s0[1] = {rec(k0 + k)};
       test_sph_any<V, NV, 1>(s0, base + k0 + k, o, L, a);
-    }
-  }
-}
-
-// SMEM + 2 pixels per lane: hand-scheduled packed body, 2 spheres per batch
-template <typename Fetch>
-DEVINL void anyhit_sph_pk(Fetch rec, int n, int base, const V3<v2f> &o, const V3<v2f> &L,
-                          Any (&a)[2]) {
-  auto test2 = [&](const Sph2(&S)[2], int idx) {
-    v2f b[2], q[2];
-    sph2_any_pk(S, o.x, o.y, o.z, L.x, L.y, L.z, b, q);
-    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
-                      __float_as_int(q[1].y));
-    if (ANY_LANE_RARE(m >= 0)) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          float t2;
-          if (sph_exact(comp(b[i], c), comp(q[i], c), a[c].tb, t2)) {
-            a[c].tocc = t2;
-            a[c].kocc = idx + i;
-            a[c].tb = 0.f;
-          }
-        }
-    }
-  };
-  // n is a multiple of 4 here (the caller peels the remainder)
-  for (int k0 = 0; k0 < n; k0 += kExitStride) {
-    if (!any_looking(a)) return;
-    const int m = min(kExitStride, n - k0);
-    Sph2 A[2], B[2];
-    fetch_batch(rec, k0, A);
-    for (int k = 0; k < m; k += 4) {
-      fetch_batch(rec, rec.landed(A[1].zr, k0 + k + 2), B);
-      test2(A, base + k0 + k);
-      fetch_batch(rec, rec.landed(B[1].zr, k0 + min(k + 4, m - 2)), A);
-      test2(B, base + k0 + k + 2);
     }
   }
 }

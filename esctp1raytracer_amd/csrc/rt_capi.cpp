@@ -22,8 +22,7 @@ static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNod
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevTriF *tri_f, esc::DevSphP *sph_p,
-                                  esc::DevSphPairP *sph2_p, esc::DevSphF *sph_f,
-                                  hipStream_t stream);
+                                  esc::DevSphF *sph_f, hipStream_t stream);
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
@@ -64,7 +63,6 @@ struct esc_context {
   esc::DevSph *d_sph = nullptr;
   esc::DevSphP *d_sph_p = nullptr;
   esc::DevSphPair *d_sph2 = nullptr;
-  esc::DevSphPairP *d_sph2_p = nullptr;
   esc::DevSphF *d_sph_f = nullptr;      // filter forms (rt_brute.h "FILTERS")
   esc::DevSphPairF *d_sph2_f = nullptr;
   esc::DevTriF *d_tri_f = nullptr;
@@ -430,7 +428,6 @@ int commit(esc_context *ctx, const Staged &s) {
   if ((rc = upload_vec(ctx->d_tri_n, s.tri_n, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph, s.sph, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph2, sph2, ctx->stream))) return rc;
-  if ((rc = alloc_dev(ctx->d_sph2_p, sph2.size()))) return rc;
   if ((rc = upload_vec(ctx->d_sph_mat, s.sph_mat, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_mat, s.mat, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_lights, s.lights, ctx->stream))) return rc;
@@ -618,7 +615,7 @@ void esc_context_destroy(esc_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
-                  ctx->d_sph2,   ctx->d_sph2_p, ctx->d_sph_f, ctx->d_sph2_f, ctx->d_tri_f,
+                  ctx->d_sph2,   ctx->d_sph_f, ctx->d_sph2_f, ctx->d_tri_f,
                   ctx->d_tri2_f,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits, ctx->d_sq, ctx->d_sq_ctl,
@@ -927,7 +924,6 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.sph = ctx->d_sph;
   p.sph_p = ctx->d_sph_p;
   p.sph2 = ctx->d_sph2;
-  p.sph2_p = ctx->d_sph2_p;
   p.sph_f = ctx->d_sph_f;
   p.sph2_f = ctx->d_sph2_f;
   p.tri_f = ctx->d_tri_f;
@@ -969,8 +965,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   }
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
-    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_tri_f, ctx->d_sph_p, ctx->d_sph2_p,
-                               ctx->d_sph_f, ctx->stream);
+    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_tri_f, ctx->d_sph_p, ctx->d_sph_f,
+                               ctx->stream);
     if (e) {
       set_error(std::string("k_prepare_primary launch: ") + hipGetErrorString((hipError_t)e));
       return ESC_ERR_HIP;

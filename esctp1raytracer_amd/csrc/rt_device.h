@@ -49,9 +49,6 @@ struct alignas(16) DevSphP {
 struct alignas(16) DevSphPair { // general form; pad half has r2 = -inf
   float cx[2], cy[2], cz[2], r2[2];
 };
-struct alignas(16) DevSphPairP { // primary form (per frame)
-  float ocx[2], ocy[2], ocz[2], cc[2];
-};
 
 // ---------------------------------------------------------------------------------------
 // Conservative FILTER forms of the sphere tables (rt_brute.h "filters").  The hot loops no longer
@@ -266,7 +263,6 @@ struct RenderParams {
   const DevSph *sph;
   const DevSphP *sph_p;
   const DevSphPair *sph2;    // ceil(n_sph / 2) records
-  const DevSphPairP *sph2_p; // ceil(n_sph / 2) records
   const DevSphF *sph_f;      // filter form of sph_p (per frame), n_sph records
   const DevSphPairF *sph2_f; // filter form of sph2 (per scene), ceil(n_sph / 2) records
   const DevTriF *tri_f;      // filter form of tri_p (per frame), n_tri records

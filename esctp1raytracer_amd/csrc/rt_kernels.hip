@@ -45,8 +45,7 @@ __global__ void __launch_bounds__(256)
 k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
                   DevTriF *__restrict__ tri_f, int n_tri,
                   const DevSph *__restrict__ sph, DevSphP *__restrict__ sph_p,
-                  DevSphPairP *__restrict__ sph2_p, DevSphF *__restrict__ sph_f, int n_sph,
-                  float ox, float oy, float oz) {
+                  DevSphF *__restrict__ sph_f, int n_sph, float ox, float oy, float oz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const f3 o = mk(ox, oy, oz);
   if (i < n_tri) {
@@ -95,15 +94,6 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
       F.ocz = oc.z;
       F.ccm = P.cc - ((A * A + fabsf(S.r2)) * 0x1p-19f + 0x1p-120f);
       sph_f[i] = F;
-    }
-    DevSphPairP &Q = sph2_p[i >> 1]; // same values, pair-interleaved (each thread owns a half)
-    Q.ocx[i & 1] = P.ocx;
-    Q.ocy[i & 1] = P.ocy;
-    Q.ocz[i & 1] = P.ocz;
-    Q.cc[i & 1] = P.cc;
-    if (i == n_sph - 1 && (n_sph & 1)) { // pad half: cc = +inf -> disc = -inf, never a candidate
-      Q.ocx[1] = Q.ocy[1] = Q.ocz[1] = 0.f;
-      Q.cc[1] = __builtin_huge_valf();
     }
   }
 }
@@ -335,9 +325,6 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
                                p.n_tri, dv[0], hit);
       closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p + n8}, p.n_sph - n8, p.n_tri + n8, dv,
                                  hit);
-    } else if constexpr (PX == 1) {
-      closest_sph_primary_pairs(SmemFetch<PairP>{reinterpret_cast<const PairP *>(p.sph2_p)},
-                                (p.n_sph + 1) >> 1, p.n_tri, dir[0], hit[0]);
     } else {
       closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p}, p.n_sph, p.n_tri, dv, hit);
     }
@@ -706,7 +693,7 @@ __global__ void __launch_bounds__(256) k_shadow_setup(const RenderParams p, int 
 // undecided ones are staged in LDS and leave as full chunks of the output queue (one atomic per
 // flush).  Every workgroup leaves the loop when the cursor passes the end: nothing waits on
 // another workgroup.
-constexpr int kSegBatch = 2; // chunks per wave per fetch
+constexpr int kSegBatch = 2; // chunks per wave per fetch (1: 10.59, 2: 10.23, 4: 10.36 ms per c4 frame)
 template <bool HAS_TRI, bool HAS_SPH>
 __global__ void __launch_bounds__(256) k_anyhit_segment(const RenderParams p, const SegArgs a) {
   __shared__ uint32_t stage[64 + 4 * kSegBatch * 64];
@@ -718,6 +705,8 @@ __global__ void __launch_bounds__(256) k_anyhit_segment(const RenderParams p, co
   int swept = 0; // primitives this wave swept (x64 = lane-tests)
   for (;;) {
     __syncthreads(); // n_staged / stage of the previous round; batch0 readers of the previous round
+    // (fetching the next batch early, while this one is worked on, was measured: 4.70 instead of
+    // 4.44 ms -- wave 0's ray loads queue up behind the atomic's return)
     if (tid == 0) batch0 = atomicAdd(a.cursor, 4u * kSegBatch);
     __syncthreads();
     const uint32_t c0 = batch0;
@@ -939,12 +928,11 @@ extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t ran
 // ---------------------------------------------------------------------------------------
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevTriF *tri_f, esc::DevSphP *sph_p,
-                                  esc::DevSphPairP *sph2_p, esc::DevSphF *sph_f,
-                                  hipStream_t stream) {
+                                  esc::DevSphF *sph_f, hipStream_t stream) {
   const int n = p->n_tri > p->n_sph ? p->n_tri : p->n_sph;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
-                     tri_p, tri_f, p->n_tri, p->sph, sph_p, sph2_p, sph_f, p->n_sph, p->origin[0],
+                     tri_p, tri_f, p->n_tri, p->sph, sph_p, sph_f, p->n_sph, p->origin[0],
                      p->origin[1], p->origin[2]);
   return (int)hipGetLastError();
 }
@@ -1031,9 +1019,11 @@ extern "C" int esc_launch_shade_queue(const esc::RenderParams *p, int li, int la
 extern "C" int esc_launch_primary_only(const esc::RenderParams *p, int px, hipStream_t stream) {
   if (p->n_local_rows <= 0 || p->W <= 0) return 0;
   using esc::v2f;
-  if (px == 1) launch_primary<esc::STAGE_SMEM, float, 1>(p, stream);
-  else if (px == 2) launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream);
-  else launch_primary<esc::STAGE_SMEM, v2f, 2>(p, stream);
+  // SMEM staging always carries 2 pixels per lane: that is the variant the packed filter bodies are
+  // written for; the 1- and 4-pixel variants spilled SGPRs / VGPRs to scratch and
+  // were removed.  The result does not depend on it.
+  (void)px;
+  launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream);
   return (int)hipGetLastError();
 }
 
@@ -1054,9 +1044,7 @@ extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, 
     if (between) (void)hipEventRecord(between, stream);
     hipLaunchKernelGGL((esc::k_shade<esc::STAGE_LDS>), dim3(shade_grid), dim3(256), 0, stream, *p);
   } else {
-    if (px == 1) launch_primary<esc::STAGE_SMEM, float, 1>(p, stream);
-    else if (px == 2) launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream);
-    else launch_primary<esc::STAGE_SMEM, v2f, 2>(p, stream);
+    launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream); // always 2 px: see esc_launch_primary_only
     if (between) (void)hipEventRecord(between, stream);
     hipLaunchKernelGGL((esc::k_shade<esc::STAGE_SMEM>), dim3(shade_grid), dim3(256), 0, stream, *p);
   }

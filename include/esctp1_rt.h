@@ -207,9 +207,11 @@ typedef struct {
   int32_t fixed_face;
   int32_t stage; /* ESC_STAGE_* */
   uint64_t seed;
-  int32_t pixels_per_lane; /* 0 = auto; 1, 2 or 4 pixels carried by each work-item (same row,
-                              16 columns apart).  Purely a scheduling choice: results are
-                              bit-identical for every value. */
+  int32_t pixels_per_lane; /* 0 = auto; 1, 2 or 4 pixels carried by each work-item of the primary
+                              pass (same row, 16 columns apart).  Purely a scheduling choice:
+                              results are bit-identical for every value.  Honoured by ESC_STAGE_LDS;
+                              ESC_STAGE_SMEM / AUTO always carry 2 (the variant the packed filter
+                              bodies are written for; the others spilled and were removed). */
   int32_t flags; /* ESC_RENDER_*; 0 = defaults */
 } esc_render_options;
 

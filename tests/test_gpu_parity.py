@@ -668,6 +668,40 @@ def test_bvh_two_lights_first_occluder_in_order(esc, renderer):
                         face_mode=esc.ESC_FACE_FIXED, fixed_face=1)
 
 
+@pytest.mark.parametrize("elev", [1e-2, 1e-3, 1e-4, 1e-5])
+@pytest.mark.parametrize("dist", [30.0, 300.0])
+def test_bvh_grazing_rays_on_large_triangles(esc, renderer, elev, dist):
+    """Rays that graze large triangles' planes from far away: the camera sits
+    `dist` away from a 24 x 28 floor, `elev` radians above its plane, and looks along it, so every
+    primary ray meets the floor plane at <= ~elev + fov/2 ... down to ~elev, and the image's
+    lower rows cross the floor's far and side edges at grazing incidence -- where the reference
+    arithmetic's (u, v) are dominated by rounding.  Walls and a ceiling graze the other way.
+    ESC_STAGE_BVH (tree walk and bins) must still return brute force's frame, which is the
+    oracle's."""
+    fl = np.array([[-12, 0, 4], [12, 0, 4], [12, 0, -24], [-12, 0, 4], [12, 0, -24], [-12, 0, -24]], np.float32)
+    wall = np.array([[-12, 0, 4], [-12, 0, -24], [-12, 9, -24], [-12, 0, 4], [-12, 9, -24], [-12, 9, 4]], np.float32)
+    ceil = fl[::-1].copy()
+    ceil[:, 1] = 9.0
+    light = np.array([[-0.5, 8.9, -9.5], [0.0, 8.9, -10.5], [0.5, 8.9, -9.5]], np.float32)
+    geoms = [{"vertex": fl, "face_index": np.arange(6).reshape(2, 3), "material": ol.WHITE},
+             {"vertex": wall, "face_index": np.arange(6).reshape(2, 3), "material": ol.RED},
+             {"vertex": ceil, "face_index": np.arange(6).reshape(2, 3), "material": ol.BLUE},
+             {"vertex": light, "face_index": np.array([[0, 1, 2]]), "material": ol.LIGHT_A}]
+    rng = np.random.default_rng(5)
+    sph = np.concatenate([rng.uniform(-10, 10, (40, 1)), rng.uniform(0.3, 6, (40, 1)),
+                          rng.uniform(-22, 2, (40, 1)), rng.uniform(0.2, 0.8, (40, 1))], 1)
+    mats = np.stack([ol.material13(ka=m, kd=m) for m in rng.uniform(0.2, 0.9, (40, 3))])
+    d = ol.scene_dict(geoms, sph.astype(np.float32), mats)
+    # the camera looks along -z, slightly above the floor plane, aimed at the floor's far edge
+    eye = (0.3, float(dist * elev), 4.0 + dist)
+    look = (0.3, 0.0, -24.0)
+    W, H = 256, 144
+    ref = ol.oracle_render(d, eye, look, W, H, threads=8)
+    for stage in (esc.ESC_STAGE_AUTO, esc.ESC_STAGE_BVH):
+        gpu, u8, _ = render_both(esc, renderer, d, eye, look, W, H, stage=stage)
+        assert_bit_equal(gpu, ref, f"grazing elev={elev} dist={dist} stage={stage}")
+
+
 def test_bvh_second_light_origin_outside_the_scene_box(esc, renderer):
     """Quirk S3 with two lights: light 2's shadow ray starts at camera + dir * (t_occ - eps), where
     t_occ is light 1's occluder distance ALONG ITS SHADOW RAY.  With light 1 far away and its
