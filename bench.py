@@ -89,6 +89,10 @@ def parse():
                          "makes the opt-in acceleration structure the measured path")
     ap.add_argument("--no-accel", action="store_true",
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="N=1: also time the same K frames with two in flight on two streams "
+                         "(information only; off by default so that a rocprofv3 trace of the "
+                         "default command holds undisturbed kernel durations)")
     ap.add_argument("--gather", default="auto", choices=["auto", "f32", "u8"],
                     help="what rank 0 collects: fp32 RGB (the seam's return_image) or the PPM-"
                          "quantised bytes k_shade writes (main.cpp:676-682; 4x fewer bytes over "
@@ -374,6 +378,18 @@ def main():
                         "note": "k_shade_ms = everything after k_primary: the fused k_shade, or "
                                 "k_shadow_setup + k_anyhit_segment x segments + k_shade_finish"}
 
+    # the reference's any-hit count: one frame in index order (the default sweeps long sphere lists
+    # in another order for the last light and so executes fewer tests; the image is the same)
+    anyhit_index_order = None
+    if world == 1 and a.stage != "bvh":
+        r.synchronize()
+        r.reset_counters()
+        with torch.cuda.stream(st):
+            r.render_strips(cam, W, H, 0, 1, out_f32=None if use_u8 else local[0],
+                            out_u8=local[0] if use_u8 else None, strip_rows=S, shadows=shadows,
+                            stage=stage, flags=esc.ESC_RENDER_INDEX_ORDER)
+        anyhit_index_order = r.counters()["anyhit_tests"]
+        r.reset_counters()
     # one un-pipelined frame: launch -> complete frame resident on rank 0
     fence()
     t1 = time.perf_counter()
@@ -386,7 +402,7 @@ def main():
     # undisturbed duration): the same K frames with two in flight on two streams, which fills the
     # tail of one frame's grids with the next frame's work
     pipelined = None
-    if world == 1 and a.stage != "bvh":
+    if world == 1 and a.stage != "bvh" and a.pipelined:
         stb = torch.cuda.Stream(device=dev)
         rb = esc.Renderer(local_rank, stream=stb)
         rb.upload(scene)
@@ -435,7 +451,8 @@ def main():
         share = my_rows / H
         closest_flop = (primary / a.steps) * share * (n_tri * F_TRI + n_sph * F_SPHERE)
         f_any = (n_tri * F_TRI + n_sph * F_SPHERE) / max(n_tri + n_sph, 1)
-        anyhit_flop = (anyhit / a.steps) * share * f_any
+        ref_anyhit = anyhit_index_order if anyhit_index_order is not None else anyhit / a.steps
+        anyhit_flop = ref_anyhit * share * f_any
         tf = (closest_flop + anyhit_flop) / (roof_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/sec + frame ms, 3840x2160 / 10k spheres, at 1/2/4/8 MI355X",
@@ -470,9 +487,12 @@ def main():
                 "hit_pixels_per_frame": hits / a.steps,
                 "closest_hit_tests_per_frame": primary / a.steps * (n_tri + n_sph),
                 "anyhit_tests_per_frame": anyhit / a.steps,
+                "anyhit_tests_per_frame_index_order": anyhit_index_order,
                 "shadow_lane_efficiency": (anyhit / lane_tests) if lane_tests else None,
             },
-            "kernel": {"name": "k_primary + k_shade (one frame = both, back to back on one stream)"
+            "kernel": {"name": "one frame = k_primary + the shading kernels (fused k_shade for short "
+                               "primitive lists; k_shadow_setup + k_anyhit_segment per segment + "
+                               "k_shade_finish per light otherwise), back to back on one stream"
                                + ("" if world == 1 else "; N>1: two frames are in flight on two "
                                   "streams, so this duration includes time shared with the other frame"),
                        "avg_ms": kernel_ms,

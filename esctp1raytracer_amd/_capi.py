@@ -29,6 +29,7 @@ ESC_STAGE_BVH = 3
 ESC_MATERIAL_FLOATS = 13
 ESC_RENDER_EXACT_ONLY = 1
 ESC_RENDER_TIME_KERNELS = 2
+ESC_RENDER_INDEX_ORDER = 4
 
 
 class EscError(RuntimeError):

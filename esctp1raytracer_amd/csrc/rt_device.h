@@ -165,6 +165,10 @@ struct SegArgs { // one launch of k_anyhit_segment
   uint32_t *cursor;
   int32_t tri_first, tri_count; // triangles of this segment (tested first: index order) ...
   int32_t rec_first, rec_count; // ... then its sphere PAIR records; either count may be 0
+  // the pair tables this launch sweeps: the scene's (index order) or, for the LAST light, the
+  // copies sorted by how much of the light's sky each sphere covers (RenderParams::sph2_ord)
+  const DevSphPair *sph2;
+  const DevSphPairF *sph2_f;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -265,6 +269,11 @@ struct RenderParams {
   const DevSphPair *sph2;    // ceil(n_sph / 2) records
   const DevSphF *sph_f;      // filter form of sph_p (per frame), n_sph records
   const DevSphPairF *sph2_f; // filter form of sph2 (per scene), ceil(n_sph / 2) records
+  // Last light only (its occluder's t2 and index are never read again, quirk S3 ends there): the
+  // same pair tables in the order of decreasing solid angle seen from that light's first sample
+  // point, so that occluded rays meet AN occluder early.  nullptr: index order everywhere.
+  const DevSphPair *sph2_ord;
+  const DevSphPairF *sph2_f_ord;
   const DevTriF *tri_f;      // filter form of tri_p (per frame), n_tri records
   const DevTriPairF *tri2_f; // filter form of tri for shadow rays (per scene), ceil(n_tri / 2)
   float shadow_rho_max;      // 1-norm radius around g inside which DevTriPairF's margins hold

@@ -755,12 +755,12 @@ __global__ void __launch_bounds__(256) k_anyhit_segment(const RenderParams p, co
           if (p.use_filter) {
             const RayF rf = make_ray_filter(so, sL, p.shadow_center);
             swept += 2 * anyhit_sph_pairs_filter(
-                             SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sph2_f) + a.rec_first},
-                             SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + a.rec_first},
+                             SmemFetch<PairF>{reinterpret_cast<const PairF *>(a.sph2_f) + a.rec_first},
+                             SmemFetch<PairG>{reinterpret_cast<const PairG *>(a.sph2) + a.rec_first},
                              a.rec_count, p.n_tri + 2 * a.rec_first, so, sL, rf, aa[0]);
           } else {
             swept += 2 * anyhit_sph_pairs(
-                             SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + a.rec_first},
+                             SmemFetch<PairG>{reinterpret_cast<const PairG *>(a.sph2) + a.rec_first},
                              a.rec_count, p.n_tri + 2 * a.rec_first, so, sL, aa[0]);
           }
         }
@@ -1001,6 +1001,9 @@ extern "C" int esc_launch_shade_queue(const esc::RenderParams *p, int li, int la
     a.tri_count = segs[4 * s + 1];
     a.rec_first = segs[4 * s + 2];
     a.rec_count = segs[4 * s + 3];
+    const bool ord = last && p->sph2_ord != nullptr;
+    a.sph2 = ord ? p->sph2_ord : p->sph2;
+    a.sph2_f = ord ? p->sph2_f_ord : p->sph2_f;
     if (a.tri_count && a.rec_count)
       hipLaunchKernelGGL((esc::k_anyhit_segment<true, true>), dim3(n_wg), dim3(256), 0, stream, *p, a);
     else if (a.tri_count)

@@ -224,16 +224,26 @@ enum {
   /* Record HIP events on the context's stream around and between the frame's two kernels
    * (k_primary, k_shade); esc_last_kernel_ms reads them.  Brute-force stages only: under
    * ESC_STAGE_BVH the frame is one kernel and ms[0] is 0. */
-  ESC_RENDER_TIME_KERNELS = 2
+  ESC_RENDER_TIME_KERNELS = 2,
+  /* occlusion() (main.cpp:314-329) tests primitives in index order and returns at the first hit.
+   * For every light but the last that order is observable (the occluder's t2 moves the next
+   * light's shadow ray, quirk S3) and is kept.  For the LAST light only hit / no hit reaches the
+   * image, so long sphere lists are swept in order of decreasing solid angle seen from the light:
+   * occluded rays stop sooner, unoccluded rays still test every primitive -- same image, fewer
+   * tests.  esc_counters.anyhit_tests then counts the tests THIS order executed.  This flag keeps
+   * index order for the last light too (anyhit_tests == the reference's count). */
+  ESC_RENDER_INDEX_ORDER = 4
 };
 
 typedef struct {
   uint64_t primary_rays; /* pixels rendered */
   uint64_t hit_pixels;   /* primary rays that hit something */
   uint64_t shadow_rays;  /* occlusion() calls (main.cpp:772): hit pixels x lights */
-  uint64_t anyhit_tests; /* primitive tests those calls execute in the reference: up to and
-                            including the first occluder, else every primitive.  Under
-                            ESC_STAGE_BVH: the tests the tree walk left for still-undecided rays */
+  uint64_t anyhit_tests; /* primitive tests those calls execute: up to and including the first
+                            occluder met, else every primitive.  Equal to the reference's count
+                            whenever the sweep is in index order (always with
+                            ESC_RENDER_INDEX_ORDER; see there).  Under ESC_STAGE_BVH: the tests
+                            the tree walk left for still-undecided rays */
   uint64_t anyhit_lane_tests; /* any-hit tests the GPU actually spent lanes on (64 per wave per
                                  primitive swept, decided or idle lanes included); the ratio
                                  anyhit_tests / anyhit_lane_tests is the lane efficiency of the

@@ -194,17 +194,27 @@ def test_sphere_scenes_bit_exact(esc, renderer, config, n, shadows, stage, px):
     renderer.upload(sc)
     cam = esc.Camera.for_image(eye, look, W, H)
     st = esc.ESC_STAGE_SMEM if stage == "smem" else esc.ESC_STAGE_LDS
-    renderer.reset_counters()
-    gpu, u8 = renderer.render(cam, W, H, want_u8=True, shadows=shadows, stage=st, px=px)
-    cnt = renderer.counters()
     ref, rc = ol.oracle_render(d, eye, look, W, H, shadows=shadows, threads=8,
                                return_counters=True)
-    assert_bit_equal(gpu, ref, f"{config}/{n}/{stage}/px{px}")
-    assert np.array_equal(u8, ol.oracle_quantise(ref))
-    lane_tests = cnt.pop("anyhit_lane_tests")
-    assert cnt == rc
-    if shadows and stage == "smem":
-        assert lane_tests >= rc["anyhit_tests"]  # lanes spent >= tests the reference needs
+    # index order (the reference's): every counter equals the oracle's; default order (long
+    # sphere lists are swept by decreasing solid angle for the LAST light): same image, the other
+    # counters equal, and fewer any-hit tests
+    for flags in (esc.ESC_RENDER_INDEX_ORDER, 0):
+        renderer.reset_counters()
+        gpu, u8 = renderer.render(cam, W, H, want_u8=True, shadows=shadows, stage=st, px=px,
+                                  flags=flags)
+        cnt = renderer.counters()
+        assert_bit_equal(gpu, ref, f"{config}/{n}/{stage}/px{px}/flags{flags}")
+        assert np.array_equal(u8, ol.oracle_quantise(ref))
+        lane_tests = cnt.pop("anyhit_lane_tests")
+        if flags == esc.ESC_RENDER_INDEX_ORDER:
+            assert cnt == rc
+            if shadows and stage == "smem":
+                assert lane_tests >= rc["anyhit_tests"]  # lanes spent >= tests the reference needs
+        else:
+            tests = cnt.pop("anyhit_tests")
+            assert cnt == {k: v for k, v in rc.items() if k != "anyhit_tests"}
+            assert tests <= rc["anyhit_tests"]
     assert 0 < rc["hit_pixels"] < W * H
 
 
