@@ -328,39 +328,54 @@ DEVINL void closest_sph_primary_pk(Fetch rec, int n, int base, const V3<v2f> &d,
 //   b' = fma(ocz,dz,fma(ocy,dy,fl(ocx dx))) are both within 3.01u A of the real dot product, so
 //   b^2 <= b'^2 + 12.1u A^2; with bb = fl(b b) <= b^2 (1+u) + 2^-149 the reference's
 //   "not disc < 0"  <=>  bb >= cc  implies  b'^2 - cc + 13.3u A^2 + 2^-149 >= 0.
-//   q' = fma(b',b',-ccm) (one rounding, sign-exact) with ccm = fl(cc - 2^-19 (A2f + r2) - 2^-120),
-//   A2f = fl(A)^2 >= A^2 (1-5u): the 32u margin covers the 13.3u above, the rounding of ccm
-//   itself (<= u (A^2 + r2)) and the rounding of A2f.
+//   With ccm = fl(cc - 2^-19 (A2f + r2) - 2^-120), A2f = fl(A)^2 >= A^2 (1-5u) -- the 32u margin
+//   covers the 13.3u above, the rounding of ccm itself (<= u (A^2 + r2)) and the rounding of A2f --
+//   this is  b'^2 >= ccm.  The kernel tests it in the scaled form |b''| >= 1 (3 operations per
+//   pair + one v_max3 per sphere; sph4_primary_filter_pk below).
 //
 // Shadow pairs: rt_device.h DevSphPairF, proof next to sph_any_filter below.
 // ---------------------------------------------------------------------------------------
-struct SphF2 { // DevSphF seen as two aligned pairs: (ocx, ocy), (ocz, ccm)
-  v2f xy, zc;
+struct SphF2 { // DevSphF seen as two aligned pairs: (sx, w), (sy, sz)
+  v2f xw, yz;
 };
 
-// 4 spheres x 2 pixels: q'[i] = fma(b',b',-ccm_i), b' = fma(ocz,dz,fma(ocy,dy,ocx*dx))
-DEVINL void sph4_primary_filter_pk(const SphF2 (&s)[4], v2f dx, v2f dy, v2f dz, v2f (&q)[4]) {
-  asm("v_pk_mul_f32 %0, %[s0a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
-      "v_pk_mul_f32 %1, %[s1a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
-      "v_pk_mul_f32 %2, %[s2a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
-      "v_pk_mul_f32 %3, %[s3a], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
-      "v_pk_fma_f32 %0, %[s0a], %[y], %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-      "v_pk_fma_f32 %1, %[s1a], %[y], %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-      "v_pk_fma_f32 %2, %[s2a], %[y], %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-      "v_pk_fma_f32 %3, %[s3a], %[y], %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-      "v_pk_fma_f32 %0, %[s0b], %[z], %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
-      "v_pk_fma_f32 %1, %[s1b], %[z], %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
-      "v_pk_fma_f32 %2, %[s2b], %[z], %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
-      "v_pk_fma_f32 %3, %[s3b], %[z], %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
-      "v_pk_fma_f32 %0, %0, %0, %[s0b] op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
-      "v_pk_fma_f32 %1, %1, %1, %[s1b] op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
-      "v_pk_fma_f32 %2, %2, %2, %[s2b] op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
-      "v_pk_fma_f32 %3, %3, %3, %[s3b] op_sel:[0,0,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+// 4 spheres x 2 pixels: b''[i] = fma(sz, dz, fma(sy, dy, fma(sx, dx, w))); candidate iff |b''| >= 1.
+// Scaling the hoisted oc by 1/s (rt_device.h DevSphF) turns "b'^2 >= ccm" into "|b''| >= 1": the
+// discriminant's fourth FMA and the per-sphere constant in the comparison are gone.  |b'' - beta/s|
+// <= 5.01u A / s (2u from the scaling, 3.01u from the chain; beta = the real dot product) and the
+// unscaled chain b' of the proof above has |b' - beta| <= 3.01u A, so |b'| >= sqrt(ccm) implies
+// |b''| >= (sqrt(ccm) - 8.02u A) / s >= 1 for the s of DevSphF.
+DEVINL void sph4_primary_filter_pk(const SphF2 (&s)[4], v2f dx, v2f dy, v2f dz, v2f (&b)[4]) {
+  asm("v_pk_fma_f32 %0, %[s0a], %[x], %[s0a] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %[s1a], %[x], %[s1a] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %2, %[s2a], %[x], %[s2a] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %3, %[s3a], %[x], %[s3a] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %[s0b], %[y], %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %[s1b], %[y], %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %2, %[s2b], %[y], %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %3, %[s3b], %[y], %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %[s0b], %[z], %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %1, %[s1b], %[z], %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %2, %[s2b], %[z], %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %3, %[s3b], %[z], %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
       "s_nop 0"
-      : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
-      : [x] "v"(dx), [y] "v"(dy), [z] "v"(dz), [s0a] "s"(s[0].xy), [s0b] "s"(s[0].zc),
-        [s1a] "s"(s[1].xy), [s1b] "s"(s[1].zc), [s2a] "s"(s[2].xy), [s2b] "s"(s[2].zc),
-        [s3a] "s"(s[3].xy), [s3b] "s"(s[3].zc));
+      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+      : [x] "v"(dx), [y] "v"(dy), [z] "v"(dz), [s0a] "s"(s[0].xw), [s0b] "s"(s[0].yz),
+        [s1a] "s"(s[1].xw), [s1b] "s"(s[1].yz), [s2a] "s"(s[2].xw), [s2b] "s"(s[2].yz),
+        [s3a] "s"(s[3].xw), [s3b] "s"(s[3].yz));
+}
+
+// running max of |b''| over 4 spheres x 2 pixels (v_max3_f32 with |.| modifiers: one instruction
+// per sphere)
+DEVINL float max_abs8(const v2f (&b)[4], float m) {
+  asm("v_max3_f32 %0, %0, |%1|, |%2|\n\t"
+      "v_max3_f32 %0, %0, |%3|, |%4|\n\t"
+      "v_max3_f32 %0, %0, |%5|, |%6|\n\t"
+      "v_max3_f32 %0, %0, |%7|, |%8|"
+      : "+v"(m)
+      : "v"(b[0].x), "v"(b[0].y), "v"(b[1].x), "v"(b[1].y), "v"(b[2].x), "v"(b[2].y), "v"(b[3].x),
+        "v"(b[3].y));
+  return m;
 }
 
 // any q' >= 0 among 8 values?  raw-bit test: non-negative floats (and +NaN) are >= 0 as ints;
@@ -384,8 +399,8 @@ DEVINL void closest_sph_primary_filter(FetchF recf, FetchE rece, int n, int base
     const SphF2(&S1)[4] = reinterpret_cast<const SphF2(&)[4]>(S[4]);
     sph4_primary_filter_pk(S0, d.x, d.y, d.z, q0);
     sph4_primary_filter_pk(S1, d.x, d.y, d.z, q1);
-    const int m = max_bits8(q1, max_bits8(q0, -1));
-    if (ANY_LANE_RARE(m >= 0)) {
+    const float m = max_abs8(q1, max_abs8(q0, 0.f));
+    if (ANY_LANE_RARE(m >= 1.f)) {
       const V3<v2f> dv[1] = {d};
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -400,10 +415,10 @@ DEVINL void closest_sph_primary_filter(FetchF recf, FetchE rece, int n, int base
     SphF2 A[8], B[8];
     fetch_batch(recf, 0, A);
     for (int k = 0; k < n; k += 16) {
-      fetch_batch(recf, recf.landed(A[7].zc, min(k + 8, n - 8)), B);
+      fetch_batch(recf, recf.landed(A[7].yz, min(k + 8, n - 8)), B);
       test8(A, k);
       if (k + 8 >= n) break; // odd number of 8-blocks: B was a clamped refetch, unused
-      fetch_batch(recf, recf.landed(B[7].zc, min(k + 16, n - 8)), A);
+      fetch_batch(recf, recf.landed(B[7].yz, min(k + 16, n - 8)), A);
       test8(B, k + 8);
     }
   }

@@ -828,9 +828,15 @@ void queue_segments(int n_tri, int n_sph, std::vector<int> &segs) {
       made++;
     }
   };
+  // $ESC_QUEUE_SEG=<records> or <first>:<steady> (tuning)
   static const int env_seg = [] {
     const char *v = std::getenv("ESC_QUEUE_SEG");
     return v ? std::max(4, std::atoi(v)) : 0;
+  }();
+  static const int env_seg2 = [] {
+    const char *v = std::getenv("ESC_QUEUE_SEG");
+    const char *c = v ? std::strchr(v, ':') : nullptr;
+    return c ? std::max(4, std::atoi(c + 1)) : 0;
   }();
   const int n_rec = (n_sph + 1) / 2;
   const bool merge_tris = n_tri > 0 && n_tri <= kQueueFewTris && n_rec > 0;
@@ -840,7 +846,8 @@ void queue_segments(int n_tri, int n_sph, std::vector<int> &segs) {
   // 10.26 / 0.89, 768: 10.28 / 0.82, 1024: 10.40 / 0.79, 1536: 10.77 / 0.72 -- shorter segments
   // waste fewer lanes but re-read the survivors' rays more often; 768 keeps the speed with 7
   // launches and ~40 % less ray traffic than the short schedule
-  if (n_rec > 0) cut(false, n_rec, env_seg ? env_seg : 768, env_seg ? env_seg : 768, 4);
+  if (n_rec > 0)
+    cut(false, n_rec, env_seg ? env_seg : 768, env_seg2 ? env_seg2 : (env_seg ? env_seg : 768), 4);
   if (merge_tris) { // a floor and a light are not worth a pass over every ray of their own
     segs[first_sph + 0] = 0;
     segs[first_sph + 1] = n_tri;

@@ -58,10 +58,16 @@ struct alignas(16) DevSphPair { // general form; pad half has r2 = -inf
 // the reference arithmetic, on the exact records above.  A filter record is NOT reference data:
 // nothing computed from it reaches the image.
 // ---------------------------------------------------------------------------------------
-// primary rays (per frame): same layout as DevSphP, with ccm = cc - 2^-19 (A^2 + r2) - 2^-120,
-// A = |ocx| + |ocy| + |ocz|
+// primary rays (per frame): the hoisted oc scaled so that the test "b'^2 >= ccm" reads "|b''| >= 1":
+//   ccm = cc - 2^-19 (A^2 + r2) - 2^-120,  A = |ocx| + |ocy| + |ocz|          (the margin, rt_brute.h)
+//   s   = (fl(sqrt(ccm)) (1 - 2^-22) - 9u A) (1 - 2^-22)                       (rounded-down sqrt, less
+//                                                                               what scaling can lose)
+//   (sx, sy, sz) = oc / s,  w = 0            b'' = fma(sz, dz, fma(sy, dy, fma(sx, dx, w)))
+// A sphere with ccm <= 0 or s <= 0 (the camera inside its margin) is always a candidate:
+//   (sx, sy, sz) = 0,  w = 2.
+// Laid out (sx, w) (sy, sz): a v_pk op may read ONE scalar pair, and the first FMA needs sx and w.
 struct alignas(16) DevSphF {
-  float ocx, ocy, ocz, ccm;
+  float sx, w, sy, sz;
 };
 // shadow rays (per scene): two spheres per record like DevSphPair, centres relative to the scene
 // point `shadow_center` g: c' = fl(c - g), km = r2 - |c'|^2 + 2^-16 (|c'|^2 + r2) + tiny, rounded up.

@@ -86,13 +86,22 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
     P.ocz = oc.z;
     P.cc = dot(oc, oc) - S.r2;
     sph_p[i] = P;
-    { // filter form (rt_brute.h "FILTERS"): ccm = cc - 2^-19 (A^2 + r2) - 2^-120
+    { // filter form (rt_brute.h "FILTERS", rt_device.h DevSphF)
       const float A = (fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z);
+      const float ccm = P.cc - ((A * A + fabsf(S.r2)) * 0x1p-19f + 0x1p-120f);
       DevSphF F;
-      F.ocx = oc.x;
-      F.ocy = oc.y;
-      F.ocz = oc.z;
-      F.ccm = P.cc - ((A * A + fabsf(S.r2)) * 0x1p-19f + 0x1p-120f);
+      F.sx = F.sy = F.sz = 0.f;
+      F.w = 2.f; // always a candidate ...
+      if (ccm > 0.f) {
+        const float s = (sqrtf(ccm) * 0x1.fffff8p-1f - A * 0x1.2p-21f) * 0x1.fffff8p-1f;
+        if (s > 0.f) { // ... unless the scaled test is well defined
+          const float inv = 1.f / s;
+          F.sx = oc.x * inv;
+          F.sy = oc.y * inv;
+          F.sz = oc.z * inv;
+          F.w = 0.f;
+        }
+      }
       sph_f[i] = F;
     }
   }

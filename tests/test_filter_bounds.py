@@ -67,18 +67,32 @@ def test_primary_filter_never_rejects_a_reference_candidate(scale):
     b = ref_dot(ocx, ocy, ocz, d[:, 0], d[:, 1], d[:, 2])
     disc = f32(f32(b * b) - cc)
     ref_candidate = ~(disc < 0)
-    # filter
+    # filter, unscaled form of the proof: b'^2 >= ccm
     bf = fma(ocz, d[:, 2], fma(ocy, d[:, 1], f32(ocx * d[:, 0])))
     qf = fma(bf, bf, -ccm)
-    filt_candidate = qf >= 0
+    assert not (ref_candidate & ~(qf >= 0)).any()
+    # filter as the kernel runs it (k_prepare_primary's DevSphF + sph4_primary_filter_pk):
+    # oc scaled by 1/s, candidate iff |b''| >= 1; spheres with ccm <= 0 or s <= 0: always
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sq = np.sqrt(np.maximum(ccm, f32(0)), dtype=f32)
+        s_eff = f32(f32(f32(sq * f32(1 - 2.0 ** -22)) - f32(A * f32(9 * 2.0 ** -24))) * f32(1 - 2.0 ** -22))
+        ok = (ccm > 0) & (s_eff > 0)
+        inv = f32(f32(1) / np.where(ok, s_eff, f32(1)))
+    sx = np.where(ok, f32(ocx * inv), f32(0))
+    sy = np.where(ok, f32(ocy * inv), f32(0))
+    sz = np.where(ok, f32(ocz * inv), f32(0))
+    w = np.where(ok, f32(0), f32(2))
+
+    def scaled(dd):
+        return np.abs(fma(sz, dd[:, 2], fma(sy, dd[:, 1], fma(sx, dd[:, 0], w)))) >= 1
+
+    filt_candidate = scaled(d)
     assert ref_candidate.sum() > n // 4 and (~ref_candidate).sum() > n // 4
     missed = ref_candidate & ~filt_candidate
     assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the filter"
     # and it is a FILTER: away from the silhouette it rejects (here every ray grazes within 1 %,
     # so most are passed; a random direction must not be)
-    dr = unit(rng.normal(size=(n, 3)))
-    bf = fma(ocz, dr[:, 2], fma(ocy, dr[:, 1], f32(ocx * dr[:, 0])))
-    assert (fma(bf, bf, -ccm) >= 0).mean() < 0.25
+    assert scaled(unit(rng.normal(size=(n, 3)))).mean() < 0.25
 
 
 @pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (30.0, 0.0), (30.0, 500.0), (1000.0, 0.0)])
