@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import esctp1raytracer_amd as esc
 px = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-stage = {"smem": esc.ESC_STAGE_SMEM, "lds": esc.ESC_STAGE_LDS, "bvh": esc.ESC_STAGE_BVH}[sys.argv[2] if len(sys.argv) > 2 else "smem"]
+stage = {"auto": esc.ESC_STAGE_AUTO, "smem": esc.ESC_STAGE_SMEM, "lds": esc.ESC_STAGE_LDS,
+         "bvh": esc.ESC_STAGE_BVH}[sys.argv[2] if len(sys.argv) > 2 else "auto"]
 shadows = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
 cfg = sys.argv[4] if len(sys.argv) > 4 else "c4"
 W, H = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (3840, 2160)
