@@ -502,12 +502,83 @@ DEVINL int tri_flags(v2f A, v2f B, v2f C, int m) {
   return max3i(m, ox, oy);
 }
 
-// SMEM + 2 pixels per lane: filter over 2 triangles per step, the reference arithmetic
-// (test_tri2_primary on the exact DevTriP records) only for steps with a candidate.  n even.
-template <typename FetchF, typename FetchE>
-DEVINL void closest_tri_primary_filter(FetchF recf, FetchE rece, int n, int base, const V3<v2f> &d,
-                                       Hit (&h)[2]) {
-  auto test2 = [&](const TriF(&T)[2], int k) {
+// ---------------------------------------------------------------------------------------
+// Triangle pre-filter.  With o' = v0 + tvec (the origin the reference's numerators are taken from)
+// the line o' + t d meets the triangle's plane at X* = v0 + u* e1 + v* e2, u* = un*/det*, v* =
+// vn*/det* (exact Cramer).  The reference's fp32 numerators are within eu = 10.04u |tv||e2|,
+// ev = 5.04u |tv||e1|, ed = 10.05u |e1||e2| (1-norms) of un*, vn*, det*, and an accept needs
+// 0 < un/det <= 1+4u, 0 < vn/det, (un+vn)/det <= 1+4u; hence u* >= -Du, v* >= -Dv,
+// u* + v* <= 1 + 4u + Du + Dv with Du + Dv <= (eu + ev + 2.0001 ed) / |det*|, and X* lies within
+// (3 (Du + Dv) + 4u) emax of the triangle (clamp the negatives, rescale the sum).  So for
+//     |det*| >= tau := 3.2u (10.04 |tv||e2| + 5.04 |tv||e1| + 20.1 |e1||e2|) emax / rho
+// X* is within rho (the bounding radius around the centroid G) of the triangle, i.e. the line
+// passes within R = 2 rho of G; and |det*| < tau shows as |det'| <= tau' = tau + 10.1u |e1||e2| in
+// the filter's own FMA dot product.  A reference accept therefore raises at least one of
+//     |b''| >= 1   (sphere (G, R) in the scaled form of DevSphF, margins as for spheres)
+//     |g''| <= 1   (g'' = d . n1 / tau')
+// and only then does the triangle filter above (and, behind it, the reference arithmetic) run.
+// Slivers (rho < 2^-10 emax) are always passed on.  6 packed FMAs + 2 three-input min/max per
+// triangle per 128 rays instead of 14 + 3.
+// ---------------------------------------------------------------------------------------
+struct TriPF { // DevTriPF as four aligned pairs
+  v2f xw, yz, gxy, gz;
+};
+
+// 4 triangles x 2 pixels -> b''[i], g''[i]
+DEVINL void tri4_primary_prefilter_pk(const TriPF (&T)[4], v2f dx, v2f dy, v2f dz, v2f (&b)[4],
+                                      v2f (&g)[4]) {
+  asm("v_pk_fma_f32 %0, %[t0a], %[x], %[t0a] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %[t1a], %[x], %[t1a] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %2, %[t2a], %[x], %[t2a] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %3, %[t3a], %[x], %[t3a] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_mul_f32 %4, %[t0c], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %5, %[t1c], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %6, %[t2c], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %7, %[t3c], %[x] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %[t0b], %[y], %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %[t1b], %[y], %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %2, %[t2b], %[y], %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %3, %[t3b], %[y], %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %4, %[t0c], %[y], %4 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %5, %[t1c], %[y], %5 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %6, %[t2c], %[y], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %7, %[t3c], %[y], %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %0, %[t0b], %[z], %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %1, %[t1b], %[z], %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %2, %[t2b], %[z], %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %3, %[t3b], %[z], %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %4, %[t0d], %[z], %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %5, %[t1d], %[z], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %6, %[t2d], %[z], %6 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %7, %[t3d], %[z], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "s_nop 0"
+      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]),
+        "=&v"(g[3])
+      : [x] "v"(dx), [y] "v"(dy), [z] "v"(dz), [t0a] "s"(T[0].xw), [t0b] "s"(T[0].yz),
+        [t0c] "s"(T[0].gxy), [t0d] "s"(T[0].gz), [t1a] "s"(T[1].xw), [t1b] "s"(T[1].yz),
+        [t1c] "s"(T[1].gxy), [t1d] "s"(T[1].gz), [t2a] "s"(T[2].xw), [t2b] "s"(T[2].yz),
+        [t2c] "s"(T[2].gxy), [t2d] "s"(T[2].gz), [t3a] "s"(T[3].xw), [t3b] "s"(T[3].yz),
+        [t3c] "s"(T[3].gxy), [t3d] "s"(T[3].gz));
+}
+
+// max |b''| and min |g''| over two records x 2 pixels (one 3-input instruction per record each)
+DEVINL void maxmin_abs4(v2f b0, v2f b1, v2f g0, v2f g1, float &mx, float &mn) {
+  asm("v_max3_f32 %0, %0, |%2|, |%3|\n\t"
+      "v_min3_f32 %1, %1, |%6|, |%7|\n\t"
+      "v_max3_f32 %0, %0, |%4|, |%5|\n\t"
+      "v_min3_f32 %1, %1, |%8|, |%9|"
+      : "+v"(mx), "+v"(mn)
+      : "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y), "v"(g0.x), "v"(g0.y), "v"(g1.x), "v"(g1.y));
+}
+
+// SMEM + 2 pixels per lane: pre-filter over 4 triangles per step (double-buffered scalar fetches);
+// a flagged pair of triangles goes through the triangle filter, and what that flags through the
+// reference arithmetic (test_tri2_primary on the exact DevTriP records).  n is a multiple of 4.
+template <typename FetchP, typename FetchF, typename FetchE>
+DEVINL void closest_tri_primary_filter(FetchP recp, FetchF recf, FetchE rece, int n, int base,
+                                       const V3<v2f> &d, Hit (&h)[2]) {
+  auto level2 = [&](int k) { // triangles k, k+1
+    const TriF T[2] = {recf(k), recf(k + 1)};
     v2f A[2], B[2], C[2];
     tri2_primary_filter_pk(T, d.x, d.y, d.z, A, B, C);
     const int m = tri_flags(A[1], B[1], C[1], tri_flags(A[0], B[0], C[0], -1));
@@ -517,15 +588,27 @@ DEVINL void closest_tri_primary_filter(FetchF recf, FetchE rece, int n, int base
       test_tri2_primary<v2f, 1>(E, base + k, dv, h);
     }
   };
-  if (n >= 2) {
-    TriF A[2], B[2];
-    fetch_batch(recf, 0, A);
-    for (int k = 0; k < n; k += 4) {
-      fetch_batch(recf, recf.landed(A[1].e, min(k + 2, n - 2)), B);
-      test2(A, k);
-      if (k + 2 >= n) break;
-      fetch_batch(recf, recf.landed(B[1].e, min(k + 4, n - 2)), A);
-      test2(B, k + 2);
+  auto test4 = [&](const TriPF(&T)[4], int k) {
+    v2f b[4], g[4];
+    tri4_primary_prefilter_pk(T, d.x, d.y, d.z, b, g);
+    float mx0 = 0.f, mn0 = 2.f, mx1 = 0.f, mn1 = 2.f;
+    maxmin_abs4(b[0], b[1], g[0], g[1], mx0, mn0);
+    maxmin_abs4(b[2], b[3], g[2], g[3], mx1, mn1);
+    const bool f0 = (mx0 >= 1.f) | (mn0 <= 1.f), f1 = (mx1 >= 1.f) | (mn1 <= 1.f);
+    if (ANY_LANE_RARE(f0 | f1)) {
+      if (__builtin_amdgcn_ballot_w64(f0)) level2(k);
+      if (__builtin_amdgcn_ballot_w64(f1)) level2(k + 2);
+    }
+  };
+  if (n >= 4) {
+    TriPF A[4], B[4];
+    fetch_batch(recp, 0, A);
+    for (int k = 0; k < n; k += 8) {
+      fetch_batch(recp, recp.landed(A[3].gz, min(k + 4, n - 4)), B);
+      test4(A, k);
+      if (k + 4 >= n) break;
+      fetch_batch(recp, recp.landed(B[3].gz, min(k + 8, n - 4)), A);
+      test4(B, k + 4);
     }
   }
 }

@@ -21,7 +21,7 @@ static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNod
               "esc_bvh_node is the public face of esc::BvhNode");
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
-                                  esc::DevTriF *tri_f, esc::DevSphP *sph_p,
+                                  esc::DevTriF *tri_f, esc::DevTriPF *tri_pf, esc::DevSphP *sph_p,
                                   esc::DevSphF *sph_f, hipStream_t stream);
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
@@ -69,6 +69,8 @@ struct esc_context {
   esc::DevSphPairF *d_sph2_f_ord = nullptr;
   esc::DevTriF *d_tri_f = nullptr;
   esc::DevTriPairF *d_tri2_f = nullptr;
+  esc::DevTriPF *d_tri_pf = nullptr;       // pre-filter forms (rt_brute.h "Triangle pre-filter")
+  esc::DevTriPairPF *d_tri2_pf = nullptr;
   float shadow_center[3] = {0, 0, 0};
   float shadow_rho_max = 0.f;
   int32_t *d_sph_mat = nullptr;
@@ -420,10 +422,10 @@ int commit(esc_context *ctx, const Staged &s) {
     }
   // the LAST light's sweep order (ESC_RENDER_INDEX_ORDER switches it off): spheres by decreasing
   // solid angle r^2 / |c - P|^2 seen from its first sample point P.  Same records, permuted pair
-  // tables (exact + filter); worth it only for lists the queue form handles.
+  // tables (exact + filter); from 256 spheres up.
   std::vector<esc::DevSphPair> sph2o;
   std::vector<esc::DevSphPairF> sph2fo;
-  if (!s.lights.empty() && (int64_t)s.sph.size() + (int64_t)s.tri.size() >= 2048 && s.sph.size() >= 64) {
+  if (!s.lights.empty() && s.sph.size() >= 256) {
     const float *P = &s.light_points[4 * (size_t)s.lights.back().first_point];
     std::vector<int> ord(s.sph.size());
     std::vector<double> key(s.sph.size());
@@ -465,6 +467,7 @@ int commit(esc_context *ctx, const Staged &s) {
   if ((rc = alloc_dev(ctx->d_sph_f, s.sph.size()))) return rc;
   if ((rc = upload_vec(ctx->d_tri2_f, tri2f, ctx->stream))) return rc;
   if ((rc = alloc_dev(ctx->d_tri_f, s.tri.size()))) return rc;
+  if ((rc = alloc_dev(ctx->d_tri_pf, s.tri.size()))) return rc;
   std::memcpy(ctx->shadow_center, g, sizeof(g));
   ctx->shadow_rho_max = (float)rho;
   if ((rc = upload_vec(ctx->d_tri, s.tri, ctx->stream))) return rc;
@@ -658,7 +661,7 @@ void esc_context_destroy(esc_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
-                  ctx->d_sph2,   ctx->d_sph_f, ctx->d_sph2_f, ctx->d_sph2_ord, ctx->d_sph2_f_ord, ctx->d_tri_f,
+                  ctx->d_sph2,   ctx->d_sph_f, ctx->d_sph2_f, ctx->d_sph2_ord, ctx->d_sph2_f_ord, ctx->d_tri_f, ctx->d_tri_pf, ctx->d_tri2_pf,
                   ctx->d_tri2_f,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits, ctx->d_sq, ctx->d_sq_ctl,
@@ -990,6 +993,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     p.sph2_f_ord = index_order ? nullptr : ctx->d_sph2_f_ord;
   }
   p.tri_f = ctx->d_tri_f;
+  p.tri_pf = ctx->d_tri_pf;
+  p.tri2_pf = ctx->d_tri2_pf;
   p.tri2_f = ctx->d_tri2_f;
   p.shadow_rho_max = ctx->shadow_rho_max;
   std::memcpy(p.shadow_center, ctx->shadow_center, 12);
@@ -1028,8 +1033,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   }
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
-    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_tri_f, ctx->d_sph_p, ctx->d_sph_f,
-                               ctx->stream);
+    int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_tri_f, ctx->d_tri_pf, ctx->d_sph_p,
+                               ctx->d_sph_f, ctx->stream);
     if (e) {
       set_error(std::string("k_prepare_primary launch: ") + hipGetErrorString((hipError_t)e));
       return ESC_ERR_HIP;

@@ -96,6 +96,25 @@ struct alignas(16) DevTriPairF {
   float k1x[2], k1y[2], k1z[2], k2x[2], k2y[2], k2z[2], M[2];
 };
 
+// Triangle PRE-filters (rt_brute.h "Triangle pre-filter"): one level above the filters.  A ray the
+// reference accepts either passes within R of the triangle's centroid G or is nearly parallel to
+// its plane (|det| < tau); R and tau are chosen together so that the rounding noise of the
+// accepted (u, v) stays within one bounding radius of the triangle whenever |det| >= tau.  Both
+// tests are 3-FMA dot products against hoisted, pre-scaled vectors:
+//   |b''| >= 1   bounding sphere (G, R), scaled like DevSphF            (sx, w) (sy, sz)
+//   |g''| <= 1   g'' = d . (e2 x e1) / tau'                             (gx, gy) (gz, -)
+// primary rays, per frame:
+struct alignas(16) DevTriPF {
+  float sx, w, sy, sz;
+  float gx, gy, gz, pad;
+};
+// shadow rays, per scene, two triangles per record: the bounding spheres in DevSphPairF form
+// (centre G - g, km) followed by the scaled normals
+struct alignas(16) DevTriPairPF {
+  float cx[2], cy[2], cz[2], km[2];
+  float gx[2], gy[2], gz[2], pad[2];
+};
+
 // scene.h:11-18 Material + whether the owning geometry has normals (main.cpp:733)
 struct alignas(16) DevMat {
   float ka[3];
@@ -280,6 +299,8 @@ struct RenderParams {
   // point, so that occluded rays meet AN occluder early.  nullptr: index order everywhere.
   const DevSphPair *sph2_ord;
   const DevSphPairF *sph2_f_ord;
+  const DevTriPF *tri_pf;      // pre-filter form of tri_p (per frame), n_tri records
+  const DevTriPairPF *tri2_pf; // pre-filter form of tri for shadow rays (per scene), ceil(n_tri / 2)
   const DevTriF *tri_f;      // filter form of tri_p (per frame), n_tri records
   const DevTriPairF *tri2_f; // filter form of tri for shadow rays (per scene), ceil(n_tri / 2)
   float shadow_rho_max;      // 1-norm radius around g inside which DevTriPairF's margins hold

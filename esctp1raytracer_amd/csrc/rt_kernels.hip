@@ -43,7 +43,7 @@ namespace esc {
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
-                  DevTriF *__restrict__ tri_f, int n_tri,
+                  DevTriF *__restrict__ tri_f, DevTriPF *__restrict__ tri_pf, int n_tri,
                   const DevSph *__restrict__ sph, DevSphP *__restrict__ sph_p,
                   DevSphF *__restrict__ sph_f, int n_sph, float ox, float oy, float oz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,6 +75,44 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
       F.M = p12 * ((p12 + at * a2) + aq) * 0x1p-17f + 0x1p-120f;
       F.pad[0] = F.pad[1] = 0.f;
       tri_f[i] = F;
+      // pre-filter form (rt_brute.h "Triangle pre-filter"): bounding sphere (G, R = 2 rho + slack)
+      // seen from the ray origin o' = v0 + tv, and the normal scaled by 1 / tau'
+      const f3 s3 = (e1 + e2) * (1.f / 3.f);
+      const f3 ocg = tv - s3; // o' - G
+      const float rho = sqrtf(fmaxf(fmaxf(dot(s3, s3), dot(e1 - s3, e1 - s3)), dot(e2 - s3, e2 - s3))) *
+                        1.00001f;
+      const float emax = sqrtf(fmaxf(dot(e1, e1), dot(e2, e2))) * 1.00001f;
+      DevTriPF Q;
+      Q.sx = Q.sy = Q.sz = 0.f;
+      Q.w = 2.f; // always a candidate ...
+      Q.gx = Q.gy = Q.gz = Q.pad = 0.f; // ... and always "grazing" (|0| <= 1)
+      if (rho > 0x1p-10f * emax) { // ... unless the triangle is not a sliver
+        // tau: |det| >= tau keeps the accepted hit within rho of the triangle; tau' adds what the
+        // filter's own det can be off by
+        const float tau = 0x1.99999ap+1f * 0x1p-24f * ((10.04f * at * a2 + 5.04f * at * a1) + 20.1f * p12) *
+                          emax / rho;
+        const float taup = (tau + 0x1.44p+3f * 0x1p-24f * p12) * 1.00001f + 0x1p-120f; // + 10.1u P12
+        const float R = 2.f * rho + 0x1p-21f * ((at + a1) + a2); // + 8u (|tv| + |e1| + |e2|)
+        const float A = (fabsf(ocg.x) + fabsf(ocg.y)) + fabsf(ocg.z);
+        const float R2 = R * R * 1.00001f;
+        const float ccg = dot(ocg, ocg) - R2;
+        const float ccm = ccg - ((A * A + R2) * 0x1p-19f + 0x1p-120f);
+        if (ccm > 0.f) {
+          const float sc = (sqrtf(ccm) * 0x1.fffff8p-1f - A * 0x1.2p-21f) * 0x1.fffff8p-1f;
+          if (sc > 0.f) {
+            const float inv = 1.f / sc;
+            Q.sx = ocg.x * inv;
+            Q.sy = ocg.y * inv;
+            Q.sz = ocg.z * inv;
+            Q.w = 0.f;
+          }
+        }
+        const float ig = 1.f / taup;
+        Q.gx = n1.x * ig;
+        Q.gy = n1.y * ig;
+        Q.gz = n1.z * ig;
+      }
+      tri_pf[i] = Q;
     }
   }
   if (i < n_sph) {
@@ -316,8 +354,9 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   pack3<V, NV>(dir, dv);
   if (STAGE == STAGE_SMEM) {
     if constexpr (PX == 2) {
-      const int n2 = (p.use_filter && p.n_tri >= 8) ? (p.n_tri & ~1) : 0;
-      closest_tri_primary_filter(SmemFetch<TriF>{reinterpret_cast<const TriF *>(p.tri_f)},
+      const int n2 = (p.use_filter && p.n_tri >= 8) ? (p.n_tri & ~3) : 0;
+      closest_tri_primary_filter(SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tri_pf)},
+                                 SmemFetch<TriF>{reinterpret_cast<const TriF *>(p.tri_f)},
                                  SmemFetch<DevTriP>{p.tri_p}, n2, 0, dv[0], hit);
       closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p + n2}, p.n_tri - n2, n2, dv, hit);
     } else {
@@ -518,6 +557,11 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         n_any += (unsigned)n_tests;
       } else if constexpr (STAGE == STAGE_SMEM) {
         // ---- segments of the primitive list, undecided rays re-packed in between
+        // (the LAST light sweeps the spheres by decreasing solid angle when the host built that
+        // order: its occluder is never read again -- rt_device.h sph2_ord)
+        const bool ord = (li == p.n_lights - 1) && p.sph2_ord != nullptr;
+        const DevSphPair *sweep_e = ord ? p.sph2_ord : p.sph2;
+        const DevSphPairF *sweep_f = ord ? p.sph2_f_ord : p.sph2_f;
         RepackLds &R = lds_rays;
         R.ox[tid] = ro.x; R.oy[tid] = ro.y; R.oz[tid] = ro.z;
         R.lx[tid] = rL.x; R.ly[tid] = rL.y; R.lz[tid] = rL.z;
@@ -570,12 +614,12 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
             } else if (p.use_filter) {
               const RayF rf = make_ray_filter(so, sL, p.shadow_center);
               n_swept += 2 * anyhit_sph_pairs_filter(
-                                 SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sph2_f) + k0},
-                                 SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + k0},
+                                 SmemFetch<PairF>{reinterpret_cast<const PairF *>(sweep_f) + k0},
+                                 SmemFetch<PairG>{reinterpret_cast<const PairG *>(sweep_e) + k0},
                                  n_here, p.n_tri + 2 * k0, so, sL, rf, aa[0]);
             } else {
               n_swept += 2 * anyhit_sph_pairs(
-                                 SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sph2) + k0},
+                                 SmemFetch<PairG>{reinterpret_cast<const PairG *>(sweep_e) + k0},
                                  n_here, p.n_tri + 2 * k0, so, sL, aa[0]);
             }
             if (aa[0].kocc >= 0) { // rr >= 0 here: a dead lane has tb = 0 and accepts nothing
@@ -936,12 +980,12 @@ extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t ran
 // host-side launchers (called from rt_capi.cpp)
 // ---------------------------------------------------------------------------------------
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
-                                  esc::DevTriF *tri_f, esc::DevSphP *sph_p,
+                                  esc::DevTriF *tri_f, esc::DevTriPF *tri_pf, esc::DevSphP *sph_p,
                                   esc::DevSphF *sph_f, hipStream_t stream) {
   const int n = p->n_tri > p->n_sph ? p->n_tri : p->n_sph;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
-                     tri_p, tri_f, p->n_tri, p->sph, sph_p, sph_f, p->n_sph, p->origin[0],
+                     tri_p, tri_f, tri_pf, p->n_tri, p->sph, sph_p, sph_f, p->n_sph, p->origin[0],
                      p->origin[1], p->origin[2]);
   return (int)hipGetLastError();
 }
