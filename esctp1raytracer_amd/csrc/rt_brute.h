@@ -775,34 +775,114 @@ DEVINL void anyhit_tri(Fetch rec, int n, int base, const V3<V> (&o)[NV], const V
   }
 }
 
+// (the ray's filter form is shared by the sphere filter further down, which documents it)
+struct RayF { // one shadow ray in filter form, as register pairs for op_sel broadcasts
+  v2f o2xy;  // (2ax, 2ay)
+  v2f o2z_n; // (2az, nko)
+  v2f Lxy;   // (Lx, Ly)
+  v2f Lz_s;  // (Lz, ms)
+};
+DEVINL RayF make_ray_filter(f3 o, f3 L, const float (&g)[3]) {
+  const float ax = o.x - g[0], ay = o.y - g[1], az = o.z - g[2];
+  const float n = (ax * ax + ay * ay) + az * az;
+  const float s = (ax * L.x + ay * L.y) + az * L.z;
+  RayF r;
+  r.o2xy = v2f{ax + ax, ay + ay};
+  r.o2z_n = v2f{az + az, n * -0.9999847412109375f}; // -(1 - 2^-16)
+  r.Lxy = v2f{L.x, L.y};
+  r.Lz_s = v2f{L.z, -s};
+  return r;
+}
+
+struct TriPairPF { // DevTriPairPF as eight aligned pairs
+  v2f x, y, z, k, gx, gy, gz, pad;
+};
+
+// 2 pair records (4 triangles) x 1 ray: q[i] = bounding-sphere test in the form of
+// pair4_any_filter_pk (>= 0: the ray may pass within R of the centroid), g[i] = L . n1 / tau'
+DEVINL void tripair2_any_prefilter_pk(const TriPairPF (&R)[2], const RayF &r, v2f (&q)[2],
+                                      v2f (&g)[2]) {
+  v2f x0, x1;
+  asm("v_pk_fma_f32 %[y0], %[r0x], %[oxy], %[ozn] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1x], %[oxy], %[ozn] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0x], %[lxy], %[lzs] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1x], %[lxy], %[lzs] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_mul_f32 %[g0], %[r0gx], %[lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %[g1], %[r1gx], %[lxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0y], %[oxy], %[y0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1y], %[oxy], %[y1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0y], %[lxy], %[x0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1y], %[lxy], %[x1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[g0], %[r0gy], %[lxy], %[g0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[g1], %[r1gy], %[lxy], %[g1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[r0z], %[ozn], %[y0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y1], %[r1z], %[ozn], %[y1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x0], %[r0z], %[lzs], %[x0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[x1], %[r1z], %[lzs], %[x1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[g0], %[r0gz], %[lzs], %[g0] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[g1], %[r1gz], %[lzs], %[g1] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[y0], %[x0], %[x0], %[y0]\n\t"
+      "v_pk_fma_f32 %[y1], %[x1], %[x1], %[y1]\n\t"
+      "s_nop 1\n\t"
+      "v_pk_add_f32 %[y0], %[y0], %[r0k]\n\t"
+      "v_pk_add_f32 %[y1], %[y1], %[r1k]\n\t"
+      "s_nop 0"
+      : [y0] "=&v"(q[0]), [y1] "=&v"(q[1]), [g0] "=&v"(g[0]), [g1] "=&v"(g[1]), [x0] "=&v"(x0),
+        [x1] "=&v"(x1)
+      : [oxy] "v"(r.o2xy), [ozn] "v"(r.o2z_n), [lxy] "v"(r.Lxy), [lzs] "v"(r.Lz_s),
+        [r0x] "s"(R[0].x), [r0y] "s"(R[0].y), [r0z] "s"(R[0].z), [r0k] "s"(R[0].k),
+        [r0gx] "s"(R[0].gx), [r0gy] "s"(R[0].gy), [r0gz] "s"(R[0].gz), [r1x] "s"(R[1].x),
+        [r1y] "s"(R[1].y), [r1z] "s"(R[1].z), [r1k] "s"(R[1].k), [r1gx] "s"(R[1].gx),
+        [r1gy] "s"(R[1].gy), [r1gz] "s"(R[1].gz));
+}
+
 // any-hit over triangles [0, n) of `rece` through the filter (1 ray per lane): 2 pair records
 // (4 triangles) per step; a step in which any lane has a candidate -- or in which a lane's ray
 // starts outside the region the margins were computed for (`far`) -- runs the reference
 // arithmetic (test_tri_any) on the exact records, in index order.  `recf` holds ceil(n/2) pair
 // records; n_first = index of triangle 0 of this range (even).
-constexpr int kTriFilterExit = 64; // triangles between exit checks
-template <typename FetchF, typename FetchE>
-DEVINL void anyhit_tri_filter(FetchF recf, FetchE rece, int n, int base, f3 o, f3 L, const RayTF &rf,
-                              bool far, Any (&a)[1]) {
+constexpr int kTriFilterExit = 128; // triangles between exit checks
+template <typename FetchP, typename FetchF, typename FetchE>
+DEVINL void anyhit_tri_filter(FetchP recp, FetchF recf, FetchE rece, int n, int base, f3 o, f3 L,
+                              const RayF &rs, const RayTF &rf, bool far, Any (&a)[1]) {
   const V3<float> ov[1] = {{o.x, o.y, o.z}}, Lv[1] = {{L.x, L.y, L.z}};
-  const int force = far ? 0 : -1; // a far ray is a candidate for every triangle
+  const int force = far ? 0 : -1; // a far ray is a candidate for every triangle, at both levels
   auto exact = [&](int k, int cnt) {
     for (int i = 0; i < cnt; ++i) test_tri_any<float, 1>(rece(k + i), base + k + i, ov, Lv, a);
+  };
+  auto level2 = [&](int k) { // triangles k .. k+3 (two pair records): the triangle filter
+    const int r = k >> 1;
+    const TriPairF R[2] = {recf(r), recf(r + 1)};
+    v2f A[2], B[2], C[2];
+    tripair2_any_filter_pk(R, rf, A, B, C);
+    const int f0 = tri_flags(A[0], B[0], C[0], force), f1 = tri_flags(A[1], B[1], C[1], force);
+    if (ANY_LANE_RARE(max(f0, f1) >= 0)) {
+      if (__builtin_amdgcn_ballot_w64(f0 >= 0)) exact(k, 2);
+      if (__builtin_amdgcn_ballot_w64(f1 >= 0)) exact(k + 2, 2);
+    }
+  };
+  auto test4 = [&](const TriPairPF(&R)[2], int k) { // pre-filter: sphere test or nearly parallel
+    v2f q[2], g[2];
+    tripair2_any_prefilter_pk(R, rs, q, g);
+    const int mq = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                       __float_as_int(q[1].y));
+    float mn = 2.f;
+    asm("v_min3_f32 %0, %0, |%1|, |%2|\n\tv_min3_f32 %0, %0, |%3|, |%4|"
+        : "+v"(mn)
+        : "v"(g[0].x), "v"(g[0].y), "v"(g[1].x), "v"(g[1].y));
+    if (ANY_LANE_RARE((mq >= 0) | (mn <= 1.f) | far)) level2(k);
   };
   for (int k0 = 0; k0 < n; k0 += kTriFilterExit) {
     if (!__builtin_amdgcn_ballot_w64(a[0].tb > 0.f)) return;
     const int m = min(kTriFilterExit, n - k0);
     const int m4 = m & ~3;
+    // one register set, no hand prefetch: the slow paths behind it (64 + 24 more SGPRs) leave no
+    // room for a second set (measured: with two, hipcc spilled the prefetched records to VGPR
+    // lanes inside this loop); the other waves of the SIMD cover the scalar-load latency
     for (int k = 0; k < m4; k += 4) {
       const int r = (k0 + k) >> 1;
-      const TriPairF R[2] = {recf(r), recf(r + 1)};
-      v2f A[2], B[2], C[2];
-      tripair2_any_filter_pk(R, rf, A, B, C);
-      const int f0 = tri_flags(A[0], B[0], C[0], force), f1 = tri_flags(A[1], B[1], C[1], force);
-      if (ANY_LANE_RARE(max(f0, f1) >= 0)) {
-        if (__builtin_amdgcn_ballot_w64(f0 >= 0)) exact(k0 + k, 2);
-        if (__builtin_amdgcn_ballot_w64(f1 >= 0)) exact(k0 + k + 2, 2);
-      }
+      const TriPairPF R[2] = {recp(r), recp(r + 1)};
+      test4(R, k0 + k);
     }
     if (m4 < m) exact(k0 + m4, m - m4);
   }
@@ -951,24 +1031,6 @@ DEVINL int anyhit_sph_pairs(Fetch rec, int n_rec, int base, f3 o, f3 L, Any &a) 
 struct PairF { // DevSphPairF as four aligned pairs
   v2f x, y, z, k;
 };
-struct RayF { // one shadow ray in filter form, as register pairs for op_sel broadcasts
-  v2f o2xy;  // (2ax, 2ay)
-  v2f o2z_n; // (2az, nko)
-  v2f Lxy;   // (Lx, Ly)
-  v2f Lz_s;  // (Lz, ms)
-};
-DEVINL RayF make_ray_filter(f3 o, f3 L, const float (&g)[3]) {
-  const float ax = o.x - g[0], ay = o.y - g[1], az = o.z - g[2];
-  const float n = (ax * ax + ay * ay) + az * az;
-  const float s = (ax * L.x + ay * L.y) + az * L.z;
-  RayF r;
-  r.o2xy = v2f{ax + ax, ay + ay};
-  r.o2z_n = v2f{az + az, n * -0.9999847412109375f}; // -(1 - 2^-16)
-  r.Lxy = v2f{L.x, L.y};
-  r.Lz_s = v2f{L.z, -s};
-  return r;
-}
-
 // 4 pair records (8 spheres) x 1 ray: q[i] = (x_i^2 + y_i) + km_i; 8 independent chains, so no
 // v_pk result is consumed within the next 3 instructions (rule measured in tools/ubench)
 DEVINL void pair4_any_filter_pk(const PairF (&R)[4], const RayF &r, v2f (&q)[4]) {

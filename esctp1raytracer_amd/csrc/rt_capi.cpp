@@ -420,6 +420,61 @@ int commit(esc_context *ctx, const Staged &s) {
       F.cz[h] = c[2];
       F.km[h] = kf;
     }
+  // pre-filter form of the triangle table for shadow rays (rt_brute.h "Triangle pre-filter"):
+  // bounding sphere (G, R) in DevSphPairF form + the normal scaled by 1 / tau', in double
+  std::vector<esc::DevTriPairPF> tri2pf(tri2f.size());
+  for (size_t j = 0; j < tri2pf.size(); j++)
+    for (int h = 0; h < 2; h++) {
+      esc::DevTriPairPF &F = tri2pf[j];
+      const size_t k = 2 * j + h;
+      F.cx[h] = F.cy[h] = F.cz[h] = 0.f;
+      F.gx[h] = F.gy[h] = F.gz[h] = F.pad[h] = 0.f;
+      F.km[h] = -__builtin_huge_valf(); // pad half: never a candidate, never "nearly parallel" ...
+      if (k >= s.tri.size()) {
+        F.gx[h] = 4.f; // ... (|L . (4,4,4)| >= 4 / sqrt(3) > 1 for a unit L)
+        F.gy[h] = 4.f;
+        F.gz[h] = 4.f;
+        continue;
+      }
+      F.km[h] = __builtin_huge_valf(); // sliver: always a candidate (g'' = 0 too)
+      const esc::DevTri &t = s.tri[k];
+      const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
+      double G[3], s3[3], r0 = 0, r1 = 0, r2 = 0, l1 = 0, l2 = 0, a1 = 0, a2 = 0, av = 0;
+      for (int a = 0; a < 3; a++) {
+        s3[a] = (e1[a] + e2[a]) / 3.0;
+        G[a] = (double)t.v0[a] + s3[a];
+        r0 += s3[a] * s3[a];
+        r1 += (e1[a] - s3[a]) * (e1[a] - s3[a]);
+        r2 += (e2[a] - s3[a]) * (e2[a] - s3[a]);
+        l1 += e1[a] * e1[a];
+        l2 += e2[a] * e2[a];
+        a1 += std::fabs(e1[a]);
+        a2 += std::fabs(e2[a]);
+        av += std::fabs((double)(float)((double)t.v0[a] - g[a]));
+      }
+      const double rad = std::sqrt(std::max(r0, std::max(r1, r2)));
+      const double emax = std::sqrt(std::max(l1, l2));
+      if (!(rad > 0x1p-10 * emax)) continue;
+      const double u = 0x1p-24, at = rho + av, p12 = a1 * a2;
+      const double tau = 3.2 * u * (10.04 * at * a2 + 5.04 * at * a1 + 20.1 * p12) * emax / rad;
+      const double taup = (tau + 10.1 * u * p12) * 1.00001 + 0x1p-120;
+      const double R = 2.0 * rad + 8.0 * u * (at + a1 + a2);
+      const float c[3] = {(float)(G[0] - g[0]), (float)(G[1] - g[1]), (float)(G[2] - g[2])};
+      const double c2 = (double)c[0] * c[0] + (double)c[1] * c[1] + (double)c[2] * c[2];
+      const double R2 = R * R * 1.00001;
+      const double km = R2 - c2 + 0x1p-16 * (c2 + R2) + 0x1p-120;
+      float kf = (float)km;
+      if ((double)kf < km) kf = std::nextafterf(kf, __builtin_huge_valf());
+      F.cx[h] = c[0];
+      F.cy[h] = c[1];
+      F.cz[h] = c[2];
+      F.km[h] = kf;
+      const double n1[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2],
+                            e2[0] * e1[1] - e2[1] * e1[0]};
+      F.gx[h] = (float)(n1[0] / taup);
+      F.gy[h] = (float)(n1[1] / taup);
+      F.gz[h] = (float)(n1[2] / taup);
+    }
   // the LAST light's sweep order (ESC_RENDER_INDEX_ORDER switches it off): spheres by decreasing
   // solid angle r^2 / |c - P|^2 seen from its first sample point P.  Same records, permuted pair
   // tables (exact + filter); from 256 spheres up.
@@ -468,6 +523,7 @@ int commit(esc_context *ctx, const Staged &s) {
   if ((rc = upload_vec(ctx->d_tri2_f, tri2f, ctx->stream))) return rc;
   if ((rc = alloc_dev(ctx->d_tri_f, s.tri.size()))) return rc;
   if ((rc = alloc_dev(ctx->d_tri_pf, s.tri.size()))) return rc;
+  if ((rc = upload_vec(ctx->d_tri2_pf, tri2pf, ctx->stream))) return rc;
   std::memcpy(ctx->shadow_center, g, sizeof(g));
   ctx->shadow_rho_max = (float)rho;
   if ((rc = upload_vec(ctx->d_tri, s.tri, ctx->stream))) return rc;

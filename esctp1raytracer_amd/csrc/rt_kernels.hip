@@ -605,9 +605,11 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
               if (p.use_filter && n_here >= 8) { // k0 is even: segment lengths are
                 bool far;
                 const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
+                const RayF rs = make_ray_filter(so, sL, p.shadow_center);
                 anyhit_tri_filter(
+                    SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tri2_pf) + (k0 >> 1)},
                     SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tri2_f) + (k0 >> 1)},
-                    SmemFetch<DevTri>{p.tri + k0}, n_here, k0, so, sL, rt, far, aa);
+                    SmemFetch<DevTri>{p.tri + k0}, n_here, k0, so, sL, rs, rt, far, aa);
               } else {
                 anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri + k0}, n_here, k0, sov, sLv, aa);
               }
@@ -795,10 +797,13 @@ __global__ void __launch_bounds__(256) k_anyhit_segment(const RenderParams p, co
           if (p.use_filter && a.tri_count >= 8) { // tri_first is even (host: segments are)
             bool far;
             const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
-            anyhit_tri_filter(SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tri2_f) +
+            const RayF rs = make_ray_filter(so, sL, p.shadow_center);
+            anyhit_tri_filter(SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tri2_pf) +
+                                                   (a.tri_first >> 1)},
+                              SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tri2_f) +
                                                   (a.tri_first >> 1)},
                               SmemFetch<DevTri>{p.tri + a.tri_first}, a.tri_count, a.tri_first, so,
-                              sL, rt, far, aa);
+                              sL, rs, rt, far, aa);
           } else {
             anyhit_tri<float, 1>(SmemFetch<DevTri>{p.tri + a.tri_first}, a.tri_count, a.tri_first,
                                  sov, sLv, aa);

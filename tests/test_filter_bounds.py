@@ -286,3 +286,167 @@ def test_triangle_shadow_filter_never_rejects_a_reference_candidate(scale, size,
     assert ref_ok.sum() > n // 8 and (~ref_ok).sum() > n // 8
     missed = ref_ok & ~filt_ok
     assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the filter"
+
+
+# ------------------------------------------------------------------ triangle pre-filters
+def _tri_geometry(e1, e2):
+    e1d, e2d = e1.astype(np.float64), e2.astype(np.float64)
+    s3 = (e1d + e2d) / 3.0
+    rad = np.sqrt(np.maximum((s3 ** 2).sum(1), np.maximum(((e1d - s3) ** 2).sum(1),
+                                                          ((e2d - s3) ** 2).sum(1))))
+    emax = np.sqrt(np.maximum((e1d ** 2).sum(1), (e2d ** 2).sum(1)))
+    return s3, rad, emax
+
+
+@pytest.mark.parametrize("scale,size", [(1.0, 1.0), (30.0, 0.1), (30.0, 30.0), (1000.0, 0.01)])
+def test_triangle_primary_prefilter_never_rejects_a_reference_candidate(scale, size):
+    """k_prepare_primary's DevTriPF + tri4_primary_prefilter_pk: bounding sphere in scaled form
+    OR nearly parallel.  Mirrors the fp32 statements of the kernel."""
+    rng = np.random.default_rng(int(scale * 7 + size * 13))
+    n = 1_000_000
+    o = (rng.uniform(-1, 1, (n, 3)) * scale).astype(f32)
+    v0 = (rng.uniform(-1, 1, (n, 3)) * scale).astype(f32)
+    e1 = (rng.normal(size=(n, 3)) * size).astype(f32)
+    e2 = (rng.normal(size=(n, 3)) * size).astype(f32)
+    # a third of the triangles are thin, a third of the rays nearly in-plane
+    thin = rng.uniform(size=n) < 0.33
+    e2 = np.where(thin[:, None], (e1 * rng.uniform(0.5, 2, (n, 1)) +
+                                  e2 * 10.0 ** rng.uniform(-4, -1, (n, 1))).astype(f32), e2)
+    d = rays_near_edges(rng, o, v0, e1, e2, n)
+    graze = rng.uniform(size=n) < 0.33
+    nrm = np.cross(e1.astype(np.float64), e2.astype(np.float64))
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    dd = d.astype(np.float64)
+    dd = dd - nrm * (dd * nrm).sum(1, keepdims=True) * (1 - 10.0 ** rng.uniform(-6, -1, (n, 1)))
+    d = np.where(graze[:, None], unit(dd), d)
+    dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+    tv = [f32(o[:, i] - v0[:, i]) for i in range(3)]
+    qv = ref_cross(*tv, e1[:, 0], e1[:, 1], e1[:, 2])
+    pv = ref_cross(dx, dy, dz, e2[:, 0], e2[:, 1], e2[:, 2])
+    det = ref_dot(e1[:, 0], e1[:, 1], e1[:, 2], *pv)
+    un = ref_dot(*tv, *pv)
+    vn = ref_dot(*qv, dx, dy, dz)
+    ref_ok = uv_accept(det, un, vn)
+    # k_prepare_primary, fp32 statement by statement
+    n1 = ref_cross(e2[:, 0], e2[:, 1], e2[:, 2], e1[:, 0], e1[:, 1], e1[:, 2])
+    a1, a2, at = l1(*e1.T), l1(*e2.T), l1(*tv)
+    p12 = f32(a1 * a2)
+    third = f32(1.0) / f32(3.0)
+    s3 = [f32(f32(e1[:, i] + e2[:, i]) * third) for i in range(3)]
+    ocg = [f32(tv[i] - s3[i]) for i in range(3)]
+
+    def d3(a, b):
+        return ref_dot(a[0], a[1], a[2], b[0], b[1], b[2])
+    e1s = [f32(e1[:, i] - s3[i]) for i in range(3)]
+    e2s = [f32(e2[:, i] - s3[i]) for i in range(3)]
+    rho = f32(np.sqrt(np.maximum(np.maximum(d3(s3, s3), d3(e1s, e1s)), d3(e2s, e2s)), dtype=f32) * f32(1.00001))
+    emax = f32(np.sqrt(np.maximum(d3(e1.T, e1.T), d3(e2.T, e2.T)), dtype=f32) * f32(1.00001))
+    ok_shape = rho > f32(2.0 ** -10) * emax
+    with np.errstate(all="ignore"):
+        tau = f32(f32(f32(f32(3.2) * f32(2.0 ** -24)) * f32(f32(f32(f32(10.04) * at) * a2 + f32(f32(5.04) * at) * a1) + f32(20.1) * p12)) * emax / rho)
+        taup = f32(f32(tau + f32(f32(10.125) * f32(2.0 ** -24)) * p12) * f32(1.00001) + f32(2.0 ** -120))
+        R = f32(f32(2) * rho + f32(2.0 ** -21) * f32(f32(at + a1) + a2))
+        A = l1(*ocg)
+        R2 = f32(f32(R * R) * f32(1.00001))
+        ccg = f32(d3(ocg, ocg) - R2)
+        ccm = f32(ccg - f32(f32(f32(A * A) + R2) * f32(2.0 ** -19) + f32(2.0 ** -120)))
+        sq = np.sqrt(np.maximum(ccm, f32(0)), dtype=f32)
+        sc = f32(f32(f32(sq * f32(1 - 2.0 ** -22)) - f32(A * f32(9 * 2.0 ** -24))) * f32(1 - 2.0 ** -22))
+        ok = ok_shape & (ccm > 0) & (sc > 0)
+        inv = f32(f32(1) / np.where(ok, sc, f32(1)))
+        ig = f32(f32(1) / np.where(ok_shape, taup, f32(1)))
+    sx = np.where(ok, f32(ocg[0] * inv), f32(0))
+    sy = np.where(ok, f32(ocg[1] * inv), f32(0))
+    sz = np.where(ok, f32(ocg[2] * inv), f32(0))
+    w = np.where(ok, f32(0), f32(2))
+    gx = np.where(ok_shape, f32(n1[0] * ig), f32(0))
+    gy = np.where(ok_shape, f32(n1[1] * ig), f32(0))
+    gz = np.where(ok_shape, f32(n1[2] * ig), f32(0))
+    b = fma(sz, dz, fma(sy, dy, fma(sx, dx, w)))
+    gg = fma(gz, dz, fma(gy, dy, f32(gx * dx)))
+    passed = (np.abs(b) >= 1) | (np.abs(gg) <= 1)
+    assert ref_ok.sum() > n // 16
+    missed = ref_ok & ~passed
+    assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the pre-filter"
+    # it filters: random directions mostly fail for small triangles -- unless they are so far away
+    # (|tv| / |e| ~ 1e5) that the reference's own (u, v) noise spans them: then nearly every ray is
+    # "nearly parallel" by the bound, correctly
+    dr = unit(rng.normal(size=(n, 3)))
+    if size <= 0.1 * scale and scale / size <= 1000:
+        br = fma(sz, dr[:, 2], fma(sy, dr[:, 1], fma(sx, dr[:, 0], w)))
+        gr = fma(gz, dr[:, 2], fma(gy, dr[:, 1], f32(gx * dr[:, 0])))
+        assert ((np.abs(br) >= 1) | (np.abs(gr) <= 1))[~thin].mean() < 0.2
+
+
+@pytest.mark.parametrize("scale,size,offset", [(1.0, 1.0, 0.0), (30.0, 0.1, 0.0), (30.0, 5.0, 800.0)])
+def test_triangle_shadow_prefilter_never_rejects_a_reference_candidate(scale, size, offset):
+    """commit()'s DevTriPairPF + make_ray_filter + tripair2_any_prefilter_pk: bounding sphere in
+    the shadow-sphere filter's form OR nearly parallel, for arbitrary origins inside rho_max."""
+    rng = np.random.default_rng(int(scale * 3 + size * 17 + offset))
+    n = 1_000_000
+    o = (rng.uniform(-1, 1, (n, 3)) * scale + offset).astype(f32)
+    v0 = (rng.uniform(-1, 1, (n, 3)) * scale + offset).astype(f32)
+    e1 = (rng.normal(size=(n, 3)) * size).astype(f32)
+    e2 = (rng.normal(size=(n, 3)) * size).astype(f32)
+    thin = rng.uniform(size=n) < 0.33
+    e2 = np.where(thin[:, None], (e1 * rng.uniform(0.5, 2, (n, 1)) +
+                                  e2 * 10.0 ** rng.uniform(-4, -1, (n, 1))).astype(f32), e2)
+    L = rays_near_edges(rng, o, v0, e1, e2, n)
+    graze = rng.uniform(size=n) < 0.33
+    nrm = np.cross(e1.astype(np.float64), e2.astype(np.float64))
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    dd = L.astype(np.float64)
+    dd = dd - nrm * (dd * nrm).sum(1, keepdims=True) * (1 - 10.0 ** rng.uniform(-6, -1, (n, 1)))
+    L = np.where(graze[:, None], unit(dd), L)
+    Lx, Ly, Lz = L[:, 0], L[:, 1], L[:, 2]
+    pv = ref_cross(Lx, Ly, Lz, e2[:, 0], e2[:, 1], e2[:, 2])
+    det = ref_dot(e1[:, 0], e1[:, 1], e1[:, 2], *pv)
+    tv = [f32(o[:, i] - v0[:, i]) for i in range(3)]
+    un = ref_dot(*tv, *pv)
+    qv = ref_cross(*tv, e1[:, 0], e1[:, 1], e1[:, 2])
+    vn = ref_dot(Lx, Ly, Lz, *qv)
+    ref_ok = uv_accept(det, un, vn)
+    # host side (commit()), double
+    pts = np.concatenate([v0, v0 + e1, v0 + e2]).astype(np.float64)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    g = (0.5 * (lo + hi)).astype(f32)
+    rho = 2.0 * np.maximum(hi - g, g - lo).sum() + 1e-30
+    e1d, e2d = e1.astype(np.float64), e2.astype(np.float64)
+    s3, rad, emax = _tri_geometry(e1, e2)
+    G = v0.astype(np.float64) + s3
+    a1, a2 = np.abs(e1d).sum(1), np.abs(e2d).sum(1)
+    av = np.abs((v0.astype(np.float64) - g).astype(f32).astype(np.float64)).sum(1)
+    u = 2.0 ** -24
+    at, p12 = rho + av, a1 * a2
+    ok_shape = rad > 2.0 ** -10 * emax
+    with np.errstate(all="ignore"):
+        tau = 3.2 * u * (10.04 * at * a2 + 5.04 * at * a1 + 20.1 * p12) * emax / rad
+    taup = (tau + 10.1 * u * p12) * 1.00001 + 2.0 ** -120
+    R = 2.0 * rad + 8.0 * u * (at + a1 + a2)
+    c = (G - g).astype(f32)
+    c2 = (c.astype(np.float64) ** 2).sum(1)
+    R2 = R * R * 1.00001
+    km_d = R2 - c2 + 2.0 ** -16 * (c2 + R2) + 2.0 ** -120
+    km = km_d.astype(f32)
+    low = km.astype(np.float64) < km_d
+    km[low] = np.nextafter(km[low], f32(np.inf))
+    km = np.where(ok_shape, km, f32(np.inf))
+    n1 = np.cross(e2d, e1d)
+    with np.errstate(all="ignore"):
+        gv = np.where(ok_shape[:, None], (n1 / taup[:, None]), 0.0).astype(f32)
+    cc = np.where(ok_shape[:, None], c, f32(0))
+    # device side: make_ray_filter + tripair2_any_prefilter_pk
+    ax, ay, az = f32(o[:, 0] - g[0]), f32(o[:, 1] - g[1]), f32(o[:, 2] - g[2])
+    assert float((np.abs(ax) + np.abs(ay) + np.abs(az)).max()) <= rho
+    nn = ref_dot(ax, ay, az, ax, ay, az)
+    ss = ref_dot(ax, ay, az, Lx, Ly, Lz)
+    nko = f32(nn * f32(-(1.0 - 2.0 ** -16)))
+    y = fma(cc[:, 2], f32(az + az), fma(cc[:, 1], f32(ay + ay), fma(cc[:, 0], f32(ax + ax), nko)))
+    x = fma(cc[:, 2], Lz, fma(cc[:, 1], Ly, fma(cc[:, 0], Lx, f32(-ss))))
+    with np.errstate(all="ignore"):
+        q = f32(fma(x, x, y) + km)
+    gg = fma(gv[:, 2], Lz, fma(gv[:, 1], Ly, f32(gv[:, 0] * Lx)))
+    passed = (q >= 0) | (np.abs(gg) <= 1)
+    assert ref_ok.sum() > n // 16
+    missed = ref_ok & ~passed
+    assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the pre-filter"
