@@ -30,6 +30,8 @@ ESC_MATERIAL_FLOATS = 13
 ESC_RENDER_EXACT_ONLY = 1
 ESC_RENDER_TIME_KERNELS = 2
 ESC_RENDER_INDEX_ORDER = 4
+ESC_RENDER_SHADE_QUEUE = 8
+ESC_RENDER_SHADE_FUSED = 16
 
 
 class EscError(RuntimeError):

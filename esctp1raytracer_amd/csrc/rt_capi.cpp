@@ -862,6 +862,11 @@ int esc_upload_flat(esc_context *ctx, int32_t num_triangles, const ispc_triangle
 namespace {
 
 constexpr int kQueueMinPrims = 2048; // below this the fused k_shade is used
+// ... and below this many pixels in the band: the queue form's ~10 launches cost ~35 us each, which a
+// small band (a rank's share of an 8-GPU frame) does not earn back.  Measured, rank 0's share of a
+// c4 frame on one GPU, two frames in flight (tools/rank_share_time.py), queue / fused: N=1 8.27 /
+// 8.98 ms, N=2 3.98 / 4.37, N=4 2.16 / 2.21, N=8 1.30 / 1.18
+constexpr int64_t kQueueMinPixels = 1500000;
 constexpr int kQueueMaxSegs = 48;
 constexpr int kQueueFewTris = 64;   // this few triangles ride along with the first sphere segment
 
@@ -1172,10 +1177,13 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     const char *v = std::getenv("ESC_SHADE");
     return !v ? 0 : (std::strcmp(v, "wg") == 0 ? 1 : (std::strcmp(v, "queue") == 0 ? 2 : 0));
   }();
+  const int want = (opts->flags & ESC_RENDER_SHADE_QUEUE) ? 2
+                   : (opts->flags & ESC_RENDER_SHADE_FUSED) ? 1 : shade_env;
   const bool queue_form =
-      stage == 1 && p.shadows && p.n_lights > 0 && shade_env != 1 &&
-      (shade_env == 2 || opts->stage == ESC_STAGE_AUTO) &&
-      (shade_env == 2 || (int64_t)p.n_tri + p.n_sph >= kQueueMinPrims);
+      stage == 1 && p.shadows && p.n_lights > 0 && want != 1 &&
+      (want == 2 || opts->stage == ESC_STAGE_AUTO) &&
+      (want == 2 || ((int64_t)p.n_tri + p.n_sph >= kQueueMinPrims &&
+                     (int64_t)n_local_rows * W >= kQueueMinPixels));
   if (queue_form) {
     int rc = render_shade_queue(ctx, p, px, timed ? ctx->ev[1] : nullptr);
     if (rc) return rc;

@@ -232,7 +232,13 @@ enum {
    * occluded rays stop sooner, unoccluded rays still test every primitive -- same image, fewer
    * tests.  esc_counters.anyhit_tests then counts the tests THIS order executed.  This flag keeps
    * index order for the last light too (anyhit_tests == the reference's count). */
-  ESC_RENDER_INDEX_ORDER = 4
+  ESC_RENDER_INDEX_ORDER = 4,
+  /* The shading pass has two forms with the same arithmetic: fused (one kernel, rays re-packed
+   * inside each workgroup) and queue (one launch per segment of the primitive list, rays compacted
+   * across the whole band).  By default the queue form is used for long lists (>= 2,048
+   * primitives) on large bands (>= 1.5 M pixels), where it is faster.  These force one. */
+  ESC_RENDER_SHADE_QUEUE = 8,
+  ESC_RENDER_SHADE_FUSED = 16
 };
 
 typedef struct {

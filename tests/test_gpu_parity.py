@@ -301,6 +301,51 @@ def test_filter_adversarial_scenes_vs_oracle(esc, renderer, case):
         assert ref.sum() > 0
 
 
+@pytest.mark.parametrize("form", ["queue", "fused"])
+def test_both_shading_forms_on_small_frames(esc, renderer, form):
+    """The queue form is chosen by default only for long primitive lists on large bands; force
+    each form (ESC_RENDER_SHADE_QUEUE / _FUSED) through scenes that exercise what differs between
+    them: two and three lights (t carried from light to light, quirk S3), triangles + spheres,
+    normals, a multi-face light with the hashed face choice, ragged sizes, cyclic strips."""
+    import torch
+    from esctp1raytracer_amd import multigpu
+    flags = esc.ESC_RENDER_SHADE_QUEUE if form == "queue" else esc.ESC_RENDER_SHADE_FUSED
+    rng = np.random.default_rng(17)
+    base = ol.load_dump("two")  # floor, a smooth-normal geometry, two lights
+    sph = np.concatenate([rng.uniform(-1.5, 1.5, (300, 1)), rng.uniform(0.1, 1.8, (300, 1)),
+                          rng.uniform(-1.5, 1.0, (300, 1)), rng.uniform(0.03, 0.2, (300, 1))], 1)
+    mats = np.stack([ol.material13(ka=c, kd=c) for c in rng.uniform(0.2, 0.9, (300, 3))])
+    third = {"vertex": np.array([[-1.8, 1.6, 1.2], [-1.8, 1.9, 1.2], [-1.5, 1.6, 1.0]], np.float32),
+             "face_index": np.array([[0, 1, 2]]), "material": ol.LIGHT_B}
+    for geoms, (W, H) in ((base["geometry"], (200, 117)), (base["geometry"] + [third], (97, 61))):
+        d = ol.scene_dict([dict(g) for g in geoms], sph.astype(np.float32), mats)
+        for index_order in (0, esc.ESC_RENDER_INDEX_ORDER):
+            gpu, u8, ref = render_both(esc, renderer, d, (0, 1, 3), (0, 1, 0), W, H,
+                                       flags=flags | index_order)
+            assert_bit_equal(gpu, ref, f"{form}/{len(d['light_sources'])} lights/{index_order}")
+            assert np.array_equal(u8, ol.oracle_quantise(ref))
+    # a two-face light with the hashed face choice, triangles only
+    d = ol.load_dump("CornellBox-Original")
+    gpu, _, ref = render_both(esc, renderer, d, (0, 1, 2), (0, 1, 0), 128, 96,
+                              face_mode=esc.ESC_FACE_HASH, seed=5, flags=flags)
+    assert_bit_equal(gpu, ref, f"{form}/hashed faces")
+    # cyclic strips (the multi-GPU partition) through the same form
+    sc, dd = synthetic_dict(esc, "c3", 300)
+    eye, look = esc.synthetic_view()
+    W, H = 136, 77
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    ref = ol.oracle_render(dd, eye, look, W, H, threads=8)
+    world = 3
+    rows = multigpu.max_local_rows(H, world)
+    gathered = torch.zeros(world, rows * W * 3, dtype=torch.float32, device="cuda:0")
+    for rank in range(world):
+        renderer.render_strips(cam, W, H, rank, world, out_f32=gathered[rank], flags=flags)
+    renderer.synchronize()
+    frame = multigpu.assemble_frame_torch(gathered, world, W, H).cpu().numpy()
+    assert_bit_equal(frame, ref, f"{form}/strips")
+
+
 def test_mixed_triangles_and_spheres(esc, renderer):
     d = ol.load_dump("two")
     rng = np.random.default_rng(5)
