@@ -146,6 +146,7 @@ SIGNATURES = {
     "esc_scene_build_accel": (C.c_int, [_P, _F, C.c_int32, C.POINTER(esc_accel_info),
                                         C.POINTER(esc_bvh_node), C.c_int64, _I32, C.c_int64, _F,
                                         C.c_int64]),
+    "esc_queue_schedule": (C.c_int, [C.c_int32, C.c_int32, _I32, C.c_int32]),
     "esc_last_kernel_ms": (C.c_int, [_P, _F]),
     "esc_reset_counters": (C.c_int, [_P]),
     "esc_read_counters": (C.c_int, [_P, C.POINTER(esc_counters)]),

@@ -1272,6 +1272,23 @@ int esc_assemble_strips(esc_context *ctx, const void *d_gathered, int32_t n_rank
   return ESC_OK;
 }
 
+int esc_queue_schedule(int32_t n_triangles, int32_t n_spheres, int32_t *segments,
+                       int32_t capacity) {
+  if (n_triangles < 0 || n_spheres < 0 || capacity < 0 || (capacity && !segments)) {
+    set_error("esc_queue_schedule: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  std::vector<int> segs;
+  queue_segments(n_triangles, n_spheres, segs);
+  const int n = (int)segs.size() / 4;
+  if (n > capacity) {
+    set_error("esc_queue_schedule: capacity too small");
+    return ESC_ERR_INVALID;
+  }
+  std::copy(segs.begin(), segs.end(), segments);
+  return n;
+}
+
 int esc_last_kernel_ms(esc_context *ctx, float ms[2]) {
   if (!ctx || !ms) {
     set_error("esc_last_kernel_ms: bad argument");

@@ -336,6 +336,13 @@ int esc_scene_build_accel(const esc_scene *scene, const float origin[3], int32_t
                           int32_t *order, int64_t order_cap, float *prim_boxes,
                           int64_t prim_boxes_cap);
 
+/* Host only: the segments the queue form of the shading pass cuts occlusion()'s primitive list
+ * into (main.cpp:314-329 order: triangles, then spheres).  segments receives 4 ints per segment:
+ * first triangle, triangle count, first sphere PAIR record, pair-record count (either count may
+ * be 0).  Returns the number of segments (<= capacity) or a negative error.  For inspection and
+ * tests: every primitive must be covered exactly once, in order. */
+int esc_queue_schedule(int32_t n_triangles, int32_t n_spheres, int32_t *segments,
+                       int32_t capacity);
 /* ms[0] = k_primary, ms[1] = k_shade of the last frame rendered with ESC_RENDER_TIME_KERNELS
  * (waits for that frame).  This is how bench.py prices each kernel against its own roof. */
 int esc_last_kernel_ms(esc_context *ctx, float ms[2]);

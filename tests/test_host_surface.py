@@ -37,6 +37,37 @@ def test_library_exports_every_declared_symbol(esc):
     assert declared <= exported
 
 
+@pytest.mark.parametrize("n_tri,n_sph", [(3, 10000), (0, 10000), (100353, 0), (200003, 0), (3, 2047),
+                                         (65, 1), (64, 9), (1, 0), (0, 1), (0, 0), (7, 7),
+                                         (1000, 100001), (12345, 6789)])
+def test_queue_schedule_covers_every_primitive_once_in_order(n_tri, n_sph):
+    """esc_queue_schedule: the segments the queue form sweeps.  occlusion() (main.cpp:314-329)
+    meets triangles in index order, then spheres; every primitive must be in exactly one segment,
+    segments in ascending order, triangle segments starting on even indices (pair-interleaved
+    filter records), sphere segments in whole pair records starting on multiples of 4."""
+    from esctp1raytracer_amd import _capi
+    lib = _capi.load()
+    segs = (C.c_int32 * (4 * 64))()
+    n = lib.esc_queue_schedule(n_tri, n_sph, segs, 64)
+    assert 0 <= n <= 48
+    n_rec = (n_sph + 1) // 2
+    tri_next, rec_next = 0, 0
+    for i in range(n):
+        t0, tn, r0, rn = segs[4 * i:4 * i + 4]
+        assert tn >= 0 and rn >= 0 and tn + rn > 0
+        if tn:
+            assert t0 == tri_next and t0 % 2 == 0
+            assert rec_next == 0 or rn == 0  # triangles come before any sphere is swept
+            tri_next += tn
+        if rn:
+            assert tri_next == n_tri, "spheres before the triangles are done"
+            assert r0 == rec_next and r0 % 4 == 0
+            rec_next += rn
+    assert tri_next == n_tri and rec_next == n_rec
+    assert lib.esc_queue_schedule(n_tri, n_sph, segs, 0) < 0 or n == 0
+    assert lib.esc_queue_schedule(-1, 0, segs, 64) < 0
+
+
 def test_multi_gpu_entry_without_a_gpu_fails_loudly(esc):
     """esc_multi_create / esc_render_frame_multi_rccl on a host without a GPU: ESC_ERR_NO_DEVICE,
     never a CPU render; the RCCL probe itself must not need a device."""
