@@ -72,7 +72,7 @@ def committed_profile(config):
 # with several waves resident; packed = v_pk_mul/add/fma_f32 (two results per lane)
 CYC_PACKED, CYC_PLAIN = 4.1, 2.66
 # packed share of the VALU instructions in each hot loop (counted in the ISA, `make asm`)
-PACKED_SHARE = {"k_primary": 32 / 41, "k_shade": 32 / 37}
+PACKED_SHARE = {"k_primary": 24 / 33, "k_shade": 32 / 37}
 
 
 def parse():
