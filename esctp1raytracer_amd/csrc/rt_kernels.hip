@@ -7,14 +7,20 @@
 //   k_shade<STAGE>     main.cpp:723-789 normal + per-light shadow ray (main.cpp:314-329) + Phong
 //                      -> fp32 RGB and/or PPM-quantised bytes; under ESC_STAGE_BVH also the
 //                      closest hit (one kernel per frame)
+//   k_shadow_setup / k_anyhit_segment / k_shade_finish   the same shading pass in its queue form
+//                      (long primitive lists on large bands): one launch per segment of the
+//                      list, undecided rays compacted across the whole band in between
 //   k_assemble_strips  multi-GPU: gathered strips -> frame
-// The pieces live in rt_math.h (arithmetic vocabulary), rt_brute.h (brute-force loops) and
-// rt_accel.h (tree walk, screen / light bins and the kernels that fill them).
+// The pieces live in rt_math.h (arithmetic vocabulary), rt_brute.h (brute-force loops and the
+// conservative filters in front of them) and rt_accel.h (tree walk, screen / light bins and the
+// kernels that fill them).
 //
 // Arithmetic contract: this file MUST be compiled with -ffp-contract=off (hipcc would
 // otherwise fuse a*b+c into v_fma_f32 and flip pixels) and with
-// correctly rounded fp32 divide/sqrt (hipcc default).  Every expression is evaluated in the
-// order the reference evaluates it.  The one liberty taken: vec.h:95-101 starts its dot
+// correctly rounded fp32 divide/sqrt (hipcc default).  Every expression THAT REACHES THE IMAGE
+// is evaluated in the order the reference evaluates it; the filters of rt_brute.h use explicit
+// v_pk_fma_f32 and only decide whether that arithmetic runs for a pair.  The one liberty taken
+// with the reference expressions themselves: vec.h:95-101 starts its dot
 // product from `sum = 0`; the leading `0 +` is dropped here.  That can only turn a -0 result
 // into +0, and every dot product on this path is either a sum of squares (never -0), or is
 // compared against a positive threshold / multiplied by other terms where +-0 behave alike
@@ -182,7 +188,7 @@ k_prepare_bvh(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, int n
 // The frame = two kernels on the same stream.
 //
 //   k_primary<STAGE, V, NV>  camera.h:31-34 get_ray + main.cpp:722 closest hit over every
-//                            primitive; writes one 16-byte hit record per pixel.
+//                            primitive; writes the hit planes (idx for every pixel, t / v for hits).
 //   k_shade<STAGE>           main.cpp:723-789: normal, per-light shadow ray (occlusion()) and
 //                            Phong; fp32 RGB and/or the PPM-quantised bytes.
 //
@@ -190,8 +196,9 @@ k_prepare_bvh(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p, int n
 // split because the two halves want different things: the primary pass is fastest with 2 pixels
 // per lane (every primitive fetch feeds 128 rays), the shadow pass with 1 (a wave retires as
 // soon as its 64 rays are decided) plus re-packing, and fused they held so many values live
-// across the hot loops that hipcc spilled SGPRs inside them.  The hand-over costs 133 MB of
-// writes + reads per 4K frame (~0.05 ms) and one kernel boundary (~1.5 us).
+// across the hot loops that hipcc spilled SGPRs inside them.  The hand-over (hit planes: an index
+// per pixel, t -- and v when normals exist -- per hit pixel) costs ~55 MB of writes + reads per 4K
+// frame and one kernel boundary.
 //
 // 256 threads = 4 waves; a wave covers (16*PX) x 4 pixels, a workgroup a (32*PX) x 8 tile.
 // ---------------------------------------------------------------------------------------
@@ -704,7 +711,8 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
 // tested (which wave, next to which other rays) differs.
 // ---------------------------------------------------------------------------------------
 
-// main.cpp:723-766 for light `li`: normal of the hit (first light only), light sample, shadow ray.
+// main.cpp:740-766 for light `li`: light sample and shadow ray of every hit pixel (the normal,
+// main.cpp:723-738, is computed by k_shade_finish for the pixels that turn out unoccluded).
 template <bool MULTI>
 __global__ void __launch_bounds__(256) k_shadow_setup(const RenderParams p, int li) {
   const Tile<1> T(p);
@@ -1088,7 +1096,7 @@ extern "C" int esc_launch_primary_only(const esc::RenderParams *p, int px, hipSt
   return (int)hipGetLastError();
 }
 
-// stage: 1 SMEM, 2 LDS, 3 BVH (px ignored).  px: pixels per work-item of the primary pass (1, 2 or 4); the shade
+// stage: 1 SMEM (always 2 px), 2 LDS, 3 BVH (px ignored).  px: pixels per work-item of the LDS primary pass (1, 2 or 4); the shade
 // pass always carries one pixel per work-item.
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, hipStream_t stream,
                                  hipEvent_t between) {
