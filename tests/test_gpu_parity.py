@@ -346,6 +346,32 @@ def test_both_shading_forms_on_small_frames(esc, renderer, form):
     assert_bit_equal(frame, ref, f"{form}/strips")
 
 
+def test_per_kernel_timing_events(esc, renderer):
+    """ESC_RENDER_TIME_KERNELS / esc_last_kernel_ms: what bench.py's `kernels` view is built on.
+    Both shading forms report two positive durations that add up to about the frame's own time;
+    without the flag the call is refused instead of returning stale numbers."""
+    import time
+    sc = esc.Scene.synthetic("c4", 3000)
+    eye, look = esc.synthetic_view()
+    W, H = 960, 540
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    ref = renderer.render(cam, W, H)
+    for form in (esc.ESC_RENDER_SHADE_QUEUE, esc.ESC_RENDER_SHADE_FUSED):
+        renderer.render(cam, W, H, flags=form)  # warm
+        renderer.synchronize()
+        t0 = time.perf_counter()
+        img = renderer.render(cam, W, H, flags=form | esc.ESC_RENDER_TIME_KERNELS)
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        prim, shade = renderer.last_kernel_ms()
+        assert_bit_equal(img, ref, "timed frame")
+        assert prim > 0 and shade > 0
+        assert prim + shade < wall_ms  # the host call also copies the frame back
+    renderer.render(cam, W, H)
+    with pytest.raises(esc.EscError):
+        renderer.last_kernel_ms()
+
+
 def test_mixed_triangles_and_spheres(esc, renderer):
     d = ol.load_dump("two")
     rng = np.random.default_rng(5)
