@@ -68,11 +68,15 @@ def committed_profile(config):
     return prof
 
 
-# measured on this chip (tools/ubench/valu_rate.hip): cycles one SIMD needs per wave64 instruction
-# with several waves resident; packed = v_pk_mul/add/fma_f32 (two results per lane)
-CYC_PACKED, CYC_PLAIN = 4.1, 2.66
-# packed share of the VALU instructions in each hot loop (counted in the ISA, `make asm`)
-PACKED_SHARE = {"k_primary": 24 / 33, "k_shade": 32 / 37}
+# Issue cost of one wave64 instruction on one SIMD with several waves resident, in cycles at the
+# nominal 2.4 GHz, measured on this chip: plain VALU and v_pk_mul/add_f32 by tools/ubench/
+# valu_rate.hip; v_pk_fma_f32 with one SGPR-pair operand by tools/ubench/filter_rate.hip (mode 3,
+# the primary filter's loop from registers: 144.9 cycles per 24 v_pk_fma + 9 plain).  A
+# v_pk_fma_f32 with three VGPR-pair operands costs 8.1 -- the filters have none in their loops.
+CYC_PLAIN, CYC_PK, CYC_PK_FMA = 2.66, 4.1, 5.04
+# VALU instruction mix of each hot loop (counted in the ISA, `make asm`): (pk_fma, pk mul/add, plain)
+LOOP_MIX = {"k_primary": (24, 0, 9),   # per 8 spheres x 128 rays
+            "k_shade": (28, 4, 5)}      # per 4 pair records (8 spheres) x 64 rays
 
 
 def parse():
@@ -526,14 +530,15 @@ def main():
                 ent = {"ms": kernel_split[ms_key]}
                 if prof and name in prof.get("valu_insts_per_frame", {}):
                     insts = prof["valu_insts_per_frame"][name]
-                    share = PACKED_SHARE[name]
-                    cyc = share * CYC_PACKED + (1 - share) * CYC_PLAIN
+                    nf, npk, npl = LOOP_MIX[name]
+                    cyc = (nf * CYC_PK_FMA + npk * CYC_PK + npl * CYC_PLAIN) / (nf + npk + npl)
                     clock_ghz = prof.get("clock_ghz", 2.4)
                     avail = ent["ms"] * 1e-3 * clock_ghz * 1e9 * 1024  # SIMD-cycles
-                    ent.update({"valu_insts": insts, "packed_share": share,
+                    ent.update({"valu_insts": insts, "loop_mix_pkfma_pk_plain": [nf, npk, npl],
                                 "cycles_per_inst_at_full_issue": cyc, "clock_ghz": clock_ghz,
                                 "issue_frac": insts * cyc / avail,
-                                "lane_ops_per_s": insts * 64 * (1 + share) / (ent["ms"] * 1e-3)})
+                                "lane_ops_per_s": insts * 64 * (1 + (nf + npk) / (nf + npk + npl))
+                                / (ent["ms"] * 1e-3)})
                 ks[name] = ent
             out["kernels"] = ks
         if pipelined is not None:
