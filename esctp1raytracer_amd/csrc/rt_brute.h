@@ -425,6 +425,118 @@ DEVINL void closest_sph_primary_filter(FetchF recf, FetchE rece, int n, int base
 }
 
 // ---------------------------------------------------------------------------------------
+// Sphere GROUPS (rt_device.h SphGroups): the same scaled test on the bounding sphere (C, R) of
+// kSphGroup spheres that are neighbours in space; only groups some ray of the wave may touch have
+// their members filtered.  What R must hold -- member i's reference test does not reject at
+// `disc < 0` for a ray (o, d), |d|^2 within 8u of 1; oc_i, b, cc_i the reference's fp32 values,
+// beta_i = oc_i . d in real arithmetic, A_i = |oc_i|_1:
+//   bb >= cc_i with |b - beta_i| <= 3.01u A_i and bb <= b^2 (1+u) + 2^-149 gives
+//   cc_i <= beta_i^2 + 7.2u A_i^2 + 2^-149, and cc_i >= |oc_i|^2 - r_i^2 - 4.02u |oc_i|^2 - u r_i^2, so the
+//   line's squared distance from the point c~_i = o - oc_i is
+//   D_i^2 = |oc_i|^2 - beta_i^2 / |d|^2 <= r_i^2 (1+u) + 19.4u A_i^2 + 2^-149,
+//   D_i <= r_i (1+u) + 4.41 sqrt(u) A_i + 2^-74.
+//   c~_i is within 1.01u A_i of c_i (the rounding of oc_i), likewise C~ = o - OC of the stored
+//   centre C (A_G = |OC|_1), and A_i <= (A_G + sqrt(3) |c_i - C|)(1 + 2u).  With rgeo >= r_i +
+//   |c_i - C| for every member the line passes C~ within
+//   rgeo (1+u) + (4.41 sqrt(u) + 2.1u)(A_G + 1.74 rgeo) + 2^-74  <=  R := rgeo + 0x1.2p-10 (A_G + 2 rgeo) + 2^-60
+//   (4.41 * 2^-12 = 1.0767e-3 < 0x1.2p-10 = 1.0986e-3: 2 % to spare for evaluating R in fp32).
+// "The line passes C~ within R" is |OC|^2 - beta_G^2 / |d|^2 <= R^2, i.e. beta_G^2 >= K (1 - 8u) with
+// K = |OC|^2 - R^2 (K <= 0: the record is "always a candidate").  The record's ccm is at most
+// K - 26.8u (A_G^2 + R2) (k_prepare_groups: R2 = R^2 * 1.00001, fp32 dot and subtraction 5.1u, margin
+// 32u less the 5u of A2f) and the filter's b' has b'^2 >= beta_G^2 - 6.1u A_G^2 >= K - 14.1u A_G^2 >= ccm:
+// the scaled test |b''| >= 1 follows exactly as for a single sphere (sph4_primary_filter_pk).
+// A camera inside a member is inside (C, rgeo): K < 0, always a candidate.
+//
+// Tests happen in group order, not index order.  The reference keeps the FIRST of two equal
+// closest t (strict `t2 < *t`): the sorted exact test below accepts an equal t iff its original
+// index is lower, which is the same rule stated without reference to the order of the tests.
+// ---------------------------------------------------------------------------------------
+DEVINL void test_sph_primary_sorted(const DevSphP (&s)[4], const DevIdx4 &orig, int base,
+                                    const V3<v2f> &d, Hit (&h)[2]) {
+  v2f b[4], q[4];
+  float m = -1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b[i] = (s[i].ocx * d.x + s[i].ocy * d.y) + s[i].ocz * d.z;
+    q[i] = b[i] * b[i] - s[i].cc;
+    m = fmaxf(m, fmaxf(q[i].x, q[i].y));
+  }
+  if (ANY_LANE_RARE(!(m < 0.f))) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t2;
+        if (sph_exact_nb(comp(b[i], c), comp(q[i], c), t2)) {
+          const int id = base + orig.v[i];
+          if (t2 < h[c].t || (t2 == h[c].t && id < h[c].idx)) {
+            h[c].t = t2;
+            h[c].idx = id;
+          }
+        }
+      }
+  }
+}
+
+// n_grp is a multiple of kSphGroupStep (= 8, pad groups never pass); group g's members are the
+// sorted slots [8 g, 8 g + 8).
+template <typename FetchF, typename FetchE, typename FetchI>
+DEVINL void closest_sph_primary_groups(FetchF recg, FetchF recf, FetchE rece, FetchI reci, int n_grp,
+                                       int base, const V3<v2f> &d, Hit (&h)[2]) {
+  static_assert(kSphGroup == 8 && kSphGroupStep == 8, "8 x 8 bodies below");
+  auto members = [&](int g) {
+    SphF2 S[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) S[i] = recf(8 * g + i);
+    v2f q0[4], q1[4];
+    const SphF2(&S0)[4] = reinterpret_cast<const SphF2(&)[4]>(S[0]);
+    const SphF2(&S1)[4] = reinterpret_cast<const SphF2(&)[4]>(S[4]);
+    sph4_primary_filter_pk(S0, d.x, d.y, d.z, q0);
+    sph4_primary_filter_pk(S1, d.x, d.y, d.z, q1);
+    const float m = max_abs8(q1, max_abs8(q0, 0.f));
+    if (ANY_LANE_RARE(m >= 1.f)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        DevSphP E[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) E[i] = rece(8 * g + 4 * j + i);
+        test_sph_primary_sorted(E, reci(2 * g + j), base, d, h);
+      }
+    }
+  };
+  auto step = [&](const SphF2(&G)[8], int g0) {
+    v2f q0[4], q1[4];
+    const SphF2(&G0)[4] = reinterpret_cast<const SphF2(&)[4]>(G[0]);
+    const SphF2(&G1)[4] = reinterpret_cast<const SphF2(&)[4]>(G[4]);
+    sph4_primary_filter_pk(G0, d.x, d.y, d.z, q0);
+    sph4_primary_filter_pk(G1, d.x, d.y, d.z, q1);
+    const float m = max_abs8(q1, max_abs8(q0, 0.f));
+    if (ANY_LANE_RARE(m >= 1.f)) {
+      uint32_t mask = 0; // wave-uniform: which of the 8 groups
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const v2f q = j < 4 ? q0[j & 3] : q1[j & 3];
+        if (__builtin_amdgcn_ballot_w64(fmaxf(fabsf(q.x), fabsf(q.y)) >= 1.f) != 0) mask |= 1u << j;
+      }
+      while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        members(g0 + j);
+      }
+    }
+  };
+  SphF2 A[8], B[8];
+  fetch_batch(recg, 0, A);
+  for (int g = 0; g < n_grp; g += 16) {
+    fetch_batch(recg, recg.landed(A[7].yz, min(g + 8, n_grp - 8)), B);
+    step(A, g);
+    if (g + 8 >= n_grp) break; // odd number of steps: B was a clamped refetch, unused
+    fetch_batch(recg, recg.landed(B[7].yz, min(g + 16, n_grp - 8)), A);
+    step(B, g + 8);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Triangle FILTERS.  ray_triangle.h's accept needs (with s = sign(det), all in its own rounded
 // arithmetic):  s*un > 0,  s*vn > 0,  s*(un + vn) <= |det| (1 + 4u)   -- from u2 >= eps, v2 >= eps,
 // u2 + v2 <= 1 -- and |un|, |vn| <= |det| (1 + 4u).  In product form, free of sign logic:

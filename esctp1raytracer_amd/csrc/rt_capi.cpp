@@ -22,7 +22,7 @@ static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNod
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevTriF *tri_f, esc::DevTriPF *tri_pf, esc::DevSphP *sph_p,
-                                  esc::DevSphF *sph_f, hipStream_t stream);
+                                  esc::DevSphF *sph_f, const esc::SphGroups *sg, hipStream_t stream);
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
@@ -67,6 +67,7 @@ struct esc_context {
   esc::DevSphPairF *d_sph2_f = nullptr;
   esc::DevSphPair *d_sph2_ord = nullptr;    // last light's sweep order (rt_device.h sph2_ord)
   esc::DevSphPairF *d_sph2_f_ord = nullptr;
+  esc::SphGroups sg{};                  // sphere groups of the primary pass (all pointers owned)
   esc::DevTriF *d_tri_f = nullptr;
   esc::DevTriPairF *d_tri2_f = nullptr;
   esc::DevTriPF *d_tri_pf = nullptr;       // pre-filter forms (rt_brute.h "Triangle pre-filter")
@@ -514,8 +515,54 @@ int commit(esc_context *ctx, const Staged &s) {
       }
     }
   }
+  // sphere groups of the primary pass (rt_device.h SphGroups): spatial order, runs of kSphGroup,
+  // padded to whole sweep steps
+  std::vector<esc::DevSph> sg_sorted;
+  std::vector<esc::DevSphGroup> sg_grp;
+  std::vector<esc::DevIdx4> sg_orig;
+  if ((int)s.sph.size() >= esc::kSphGroupMinSpheres) {
+    std::vector<int32_t> order;
+    esc::group_order(s.sph, esc::kSphGroup, order);
+    const size_t n_real = (s.sph.size() + esc::kSphGroup - 1) / esc::kSphGroup;
+    const size_t n_grp = (n_real + esc::kSphGroupStep - 1) / esc::kSphGroupStep * esc::kSphGroupStep;
+    esc::DevSph pad_s;
+    pad_s.cx = pad_s.cy = pad_s.cz = 0.f;
+    pad_s.r2 = -__builtin_huge_valf();
+    sg_sorted.assign(n_grp * esc::kSphGroup, pad_s);
+    esc::DevSphGroup pad_g;
+    pad_g.cx = pad_g.cy = pad_g.cz = 0.f;
+    pad_g.rgeo = -1.f;
+    sg_grp.assign(n_grp, pad_g);
+    esc::DevIdx4 pad_i;
+    pad_i.v[0] = pad_i.v[1] = pad_i.v[2] = pad_i.v[3] = INT32_MAX / 2;
+    sg_orig.assign(n_grp * esc::kSphGroup / 4, pad_i);
+    for (size_t k = 0; k < order.size(); k++) {
+      sg_sorted[k] = s.sph[(size_t)order[k]];
+      sg_orig[k >> 2].v[k & 3] = order[k];
+    }
+    for (size_t j = 0; j < n_real; j++) {
+      const size_t first = j * esc::kSphGroup;
+      sg_grp[j] = esc::group_bounds(s.sph, order.data() + first,
+                                    (int)std::min((size_t)esc::kSphGroup, order.size() - first));
+    }
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read old tables
   int rc;
+  {
+    esc::DevSph *d_sorted = const_cast<esc::DevSph *>(ctx->sg.sorted);
+    esc::DevSphGroup *d_grp = const_cast<esc::DevSphGroup *>(ctx->sg.grp);
+    esc::DevIdx4 *d_orig = const_cast<esc::DevIdx4 *>(ctx->sg.orig);
+    if ((rc = upload_vec(d_sorted, sg_sorted, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_grp, sg_grp, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_orig, sg_orig, ctx->stream))) return rc;
+    ctx->sg.sorted = d_sorted;
+    ctx->sg.grp = d_grp;
+    ctx->sg.orig = d_orig;
+    if ((rc = alloc_dev(ctx->sg.sorted_p, sg_sorted.size()))) return rc;
+    if ((rc = alloc_dev(ctx->sg.sorted_f, sg_sorted.size()))) return rc;
+    if ((rc = alloc_dev(ctx->sg.grp_f, sg_grp.size()))) return rc;
+    ctx->sg.n_grp = (int32_t)sg_grp.size();
+  }
   if ((rc = upload_vec(ctx->d_sph2_ord, sph2o, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph2_f_ord, sph2fo, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph2_f, sph2f, ctx->stream))) return rc;
@@ -718,7 +765,9 @@ void esc_context_destroy(esc_context *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
                   ctx->d_sph2,   ctx->d_sph_f, ctx->d_sph2_f, ctx->d_sph2_ord, ctx->d_sph2_f_ord, ctx->d_tri_f, ctx->d_tri_pf, ctx->d_tri2_pf,
-                  ctx->d_tri2_f,
+                  ctx->d_tri2_f, const_cast<esc::DevSph *>(ctx->sg.sorted),
+                  const_cast<esc::DevSphGroup *>(ctx->sg.grp), const_cast<esc::DevIdx4 *>(ctx->sg.orig),
+                  ctx->sg.sorted_p, ctx->sg.sorted_f, ctx->sg.grp_f,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits, ctx->d_sq, ctx->d_sq_ctl,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
@@ -1052,6 +1101,12 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     const bool index_order = env_index || (opts->flags & ESC_RENDER_INDEX_ORDER);
     p.sph2_ord = index_order ? nullptr : ctx->d_sph2_ord;
     p.sph2_f_ord = index_order ? nullptr : ctx->d_sph2_f_ord;
+    static const bool env_nogroups = [] {
+      const char *e = std::getenv("ESC_GROUPS");
+      return e && std::strcmp(e, "0") == 0;
+    }();
+    p.sg = ctx->sg;
+    if (index_order || env_nogroups) p.sg.n_grp = 0;
   }
   p.tri_f = ctx->d_tri_f;
   p.tri_pf = ctx->d_tri_pf;
@@ -1095,7 +1150,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
     int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_tri_f, ctx->d_tri_pf, ctx->d_sph_p,
-                               ctx->d_sph_f, ctx->stream);
+                               ctx->d_sph_f, &ctx->sg, ctx->stream);
     if (e) {
       set_error(std::string("k_prepare_primary launch: ") + hipGetErrorString((hipError_t)e));
       return ESC_ERR_HIP;

@@ -76,6 +76,37 @@ struct alignas(16) DevSphPairF {
   float cx[2], cy[2], cz[2], km[2];
 };
 
+// ---------------------------------------------------------------------------------------
+// Sphere GROUPS (rt_brute.h "Sphere groups"): one more filter level in front of the sphere filter.
+// At commit the spheres are put in a spatial order (k-d median splits, host/accel_build.cpp
+// group_order) and cut into runs of kSphGroup; a run's bounding sphere (C, rgeo), enlarged per
+// frame by what the reference's own rounding can make a member reach, is tested in the same scaled
+// form as a single sphere (DevSphF), 8 groups per step, and only the members of a group some ray
+// of the wave may touch go through the per-sphere filter (and, behind it, the reference
+// arithmetic on the exact records).  The closest hit does not depend on the order of the tests
+// except between equal t, where the reference keeps the lower index: the sorted exact test
+// restores that with the original index (`orig`).  Nothing computed from a group record reaches
+// the image.
+// ---------------------------------------------------------------------------------------
+constexpr int kSphGroup = 8;          // spheres per group
+constexpr int kSphGroupStep = 8;      // groups per sweep step: n_grp is a multiple of this
+constexpr int kSphGroupMinSpheres = 64;
+struct alignas(16) DevSphGroup { // static: centre and the radius that holds every member sphere
+  float cx, cy, cz, rgeo;        // pad group: rgeo < 0
+};
+struct alignas(16) DevIdx4 {
+  int32_t v[4];
+};
+struct SphGroups {
+  int32_t n_grp, pad;        // 0: no groups (small scenes, ESC_RENDER_INDEX_ORDER, filters off)
+  const DevSph *sorted;      // n_grp * kSphGroup spheres in group order; pad slots have r2 = -inf
+  const DevSphGroup *grp;    // n_grp
+  const DevIdx4 *orig;       // original index of each sorted slot, 4 per record; pads INT32_MAX / 2
+  DevSphP *sorted_p;         // per frame: DevSphP / DevSphF of `sorted`, DevSphF of `grp`
+  DevSphF *sorted_f;
+  DevSphF *grp_f;
+};
+
 // Triangles (rt_brute.h "FILTERS", triangle part).  The reference's numerators are scalar triple
 // products: det = e1.(d x e2) = d.(e2 x e1), u-numerator = tv.(d x e2) = d.(e2 x tv), v-numerator =
 // d.qv, so with the three vectors hoisted a (ray, triangle) pair costs three FMA dot products.
@@ -316,6 +347,7 @@ struct RenderParams {
   uint8_t *out_u8;  // band-local, may be null
   // kCounterSets replicas of {primary, hit, shadow rays, any-hit tests, 4 spare}, 64 B each
   unsigned long long *counters;
+  SphGroups sg;                 // primary rays: sphere groups
   ShadeQueue sq;                // queue form of the shadow pass (brute force, large scenes)
   HitPlanes hits;               // band-local, n_local_rows * W pixels (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only

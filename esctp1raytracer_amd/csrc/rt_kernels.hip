@@ -47,6 +47,27 @@ namespace esc {
 // ---------------------------------------------------------------------------------------
 // per-frame constants for primary rays
 // ---------------------------------------------------------------------------------------
+// DevSphF of "the rays start oc away from a centre; cc = fl(fl-dot(oc, oc) - r2)": the scaled
+// filter record with the margins of rt_brute.h "FILTERS" (r2a = |r2|)
+DEVINL DevSphF sphere_filter_record(f3 oc, float cc, float r2a) {
+  const float A = (fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z);
+  const float ccm = cc - ((A * A + r2a) * 0x1p-19f + 0x1p-120f);
+  DevSphF F;
+  F.sx = F.sy = F.sz = 0.f;
+  F.w = 2.f; // always a candidate ...
+  if (ccm > 0.f) {
+    const float s = (sqrtf(ccm) * 0x1.fffff8p-1f - A * 0x1.2p-21f) * 0x1.fffff8p-1f;
+    if (s > 0.f) { // ... unless the scaled test is well defined
+      const float inv = 1.f / s;
+      F.sx = oc.x * inv;
+      F.sy = oc.y * inv;
+      F.sz = oc.z * inv;
+      F.w = 0.f;
+    }
+  }
+  return F;
+}
+
 __global__ void __launch_bounds__(256)
 k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
                   DevTriF *__restrict__ tri_f, DevTriPF *__restrict__ tri_pf, int n_tri,
@@ -130,24 +151,47 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
     P.ocz = oc.z;
     P.cc = dot(oc, oc) - S.r2;
     sph_p[i] = P;
-    { // filter form (rt_brute.h "FILTERS", rt_device.h DevSphF)
-      const float A = (fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z);
-      const float ccm = P.cc - ((A * A + fabsf(S.r2)) * 0x1p-19f + 0x1p-120f);
-      DevSphF F;
-      F.sx = F.sy = F.sz = 0.f;
-      F.w = 2.f; // always a candidate ...
-      if (ccm > 0.f) {
-        const float s = (sqrtf(ccm) * 0x1.fffff8p-1f - A * 0x1.2p-21f) * 0x1.fffff8p-1f;
-        if (s > 0.f) { // ... unless the scaled test is well defined
-          const float inv = 1.f / s;
-          F.sx = oc.x * inv;
-          F.sy = oc.y * inv;
-          F.sz = oc.z * inv;
-          F.w = 0.f;
-        }
-      }
-      sph_f[i] = F;
+    sph_f[i] = sphere_filter_record(oc, P.cc, fabsf(S.r2)); // rt_brute.h "FILTERS"
+  }
+}
+
+// per-frame records of the sphere groups (rt_device.h SphGroups): the sorted spheres' primary and
+// filter forms, and every group's bounding sphere in filter form.  R = rgeo + what the reference's
+// rounding can add to a member's reach (rt_brute.h "Sphere groups").
+__global__ void __launch_bounds__(256) k_prepare_groups(const SphGroups g, float ox, float oy, float oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const f3 o = mk(ox, oy, oz);
+  if (i < g.n_grp * kSphGroup) {
+    const DevSph S = g.sorted[i];
+    DevSphP P;
+    DevSphF F;
+    if (S.r2 == -__builtin_huge_valf()) { // pad slot: disc = -inf, b'' = 0
+      P.ocx = P.ocy = P.ocz = 0.f;
+      P.cc = __builtin_huge_valf();
+      F.sx = F.sy = F.sz = F.w = 0.f;
+    } else {
+      const f3 oc = o - mk(S.cx, S.cy, S.cz);
+      P.ocx = oc.x;
+      P.ocy = oc.y;
+      P.ocz = oc.z;
+      P.cc = dot(oc, oc) - S.r2;
+      F = sphere_filter_record(oc, P.cc, fabsf(S.r2));
     }
+    g.sorted_p[i] = P;
+    g.sorted_f[i] = F;
+  }
+  if (i < g.n_grp) {
+    const DevSphGroup G = g.grp[i];
+    DevSphF F;
+    F.sx = F.sy = F.sz = F.w = 0.f; // pad group: never a candidate
+    if (!(G.rgeo < 0.f)) {
+      const f3 oc = o - mk(G.cx, G.cy, G.cz);
+      const float A = (fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z);
+      const float R = (G.rgeo + 0x1.2p-10f * (A + 2.f * G.rgeo)) + 0x1p-60f;
+      const float R2 = R * R * 1.00001f;
+      F = sphere_filter_record(oc, dot(oc, oc) - R2, R2);
+    }
+    g.grp_f[i] = F;
   }
 }
 
@@ -371,6 +415,12 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     }
     if constexpr (PX == 2) {
       // multiples of 8 through the hand-scheduled packed bodies, the tail through the generic one
+      if (p.use_filter && p.sg.n_grp > 0) {
+        closest_sph_primary_groups(SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f)},
+                                   SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.sorted_f)},
+                                   SmemFetch<DevSphP>{p.sg.sorted_p}, SmemFetch<DevIdx4>{p.sg.orig},
+                                   p.sg.n_grp, p.n_tri, dv[0], hit);
+      } else {
       const int n8 = p.n_sph & ~7;
       if (p.use_filter)
         closest_sph_primary_filter(SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sph_f)},
@@ -380,6 +430,7 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
                                p.n_tri, dv[0], hit);
       closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p + n8}, p.n_sph - n8, p.n_tri + n8, dv,
                                  hit);
+      }
     } else {
       closest_sph_primary<V, NV>(SmemFetch<DevSphP>{p.sph_p}, p.n_sph, p.n_tri, dv, hit);
     }
@@ -994,12 +1045,15 @@ extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t ran
 // ---------------------------------------------------------------------------------------
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevTriF *tri_f, esc::DevTriPF *tri_pf, esc::DevSphP *sph_p,
-                                  esc::DevSphF *sph_f, hipStream_t stream) {
+                                  esc::DevSphF *sph_f, const esc::SphGroups *sg, hipStream_t stream) {
   const int n = p->n_tri > p->n_sph ? p->n_tri : p->n_sph;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
                      tri_p, tri_f, tri_pf, p->n_tri, p->sph, sph_p, sph_f, p->n_sph, p->origin[0],
                      p->origin[1], p->origin[2]);
+  if (sg->n_grp > 0)
+    hipLaunchKernelGGL(esc::k_prepare_groups, dim3((sg->n_grp * esc::kSphGroup + 255) / 256),
+                       dim3(256), 0, stream, *sg, p->origin[0], p->origin[1], p->origin[2]);
   return (int)hipGetLastError();
 }
 

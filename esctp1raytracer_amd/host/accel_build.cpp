@@ -488,4 +488,73 @@ void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, 
   out.depth = r.depth;
 }
 
+// ---- sphere groups of the brute-force primary pass (rt_device.h SphGroups) ----------------
+// Spatial order by k-d median splits along the longest axis of the centres; every left part is a
+// whole number of runs, so consecutive runs of `run` in the result are the leaves.  Ties are broken
+// by index: the order is a function of the scene alone.
+void group_order(const std::vector<DevSph> &sph, int run, std::vector<int32_t> &order) {
+  order.resize(sph.size());
+  std::iota(order.begin(), order.end(), 0);
+  struct Split {
+    static void go(const std::vector<DevSph> &sph, int run, int32_t *idx, size_t n) {
+      if (n <= (size_t)run) {
+        std::sort(idx, idx + n);
+        return;
+      }
+      float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+      for (size_t i = 0; i < n; i++) {
+        const DevSph &s = sph[(size_t)idx[i]];
+        const float c[3] = {s.cx, s.cy, s.cz};
+        for (int a = 0; a < 3; a++) {
+          lo[a] = std::min(lo[a], c[a]);
+          hi[a] = std::max(hi[a], c[a]);
+        }
+      }
+      int ax = 0;
+      for (int a = 1; a < 3; a++)
+        if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+      const size_t runs = (n + (size_t)run - 1) / (size_t)run;
+      const size_t left = (runs / 2) * (size_t)run; // 0 < left < n since runs >= 2
+      std::nth_element(idx, idx + left, idx + n, [&](int32_t a, int32_t b) {
+        const float ca = ax == 0 ? sph[(size_t)a].cx : ax == 1 ? sph[(size_t)a].cy : sph[(size_t)a].cz;
+        const float cb = ax == 0 ? sph[(size_t)b].cx : ax == 1 ? sph[(size_t)b].cy : sph[(size_t)b].cz;
+        return ca < cb || (ca == cb && a < b);
+      });
+      go(sph, run, idx, left);
+      go(sph, run, idx + left, n - left);
+    }
+  };
+  Split::go(sph, run, order.data(), order.size());
+}
+
+// Bounding sphere of the spheres order[first .. first + count): centre = middle of the box around
+// them (stored in fp32), rgeo >= r_i + |c_i - C| for every member, rounded up.
+DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, int count) {
+  double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  for (int i = 0; i < count; i++) {
+    const DevSph &s = sph[(size_t)order[i]];
+    const double r = std::sqrt(std::max((double)s.r2, 0.0));
+    const double c[3] = {s.cx, s.cy, s.cz};
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::min(lo[a], c[a] - r);
+      hi[a] = std::max(hi[a], c[a] + r);
+    }
+  }
+  DevSphGroup G;
+  G.cx = (float)(0.5 * (lo[0] + hi[0]));
+  G.cy = (float)(0.5 * (lo[1] + hi[1]));
+  G.cz = (float)(0.5 * (lo[2] + hi[2]));
+  double rg = 0.0;
+  for (int i = 0; i < count; i++) {
+    const DevSph &s = sph[(size_t)order[i]];
+    const double dx = (double)s.cx - G.cx, dy = (double)s.cy - G.cy, dz = (double)s.cz - G.cz;
+    rg = std::max(rg, std::sqrt(std::max((double)s.r2, 0.0)) + std::sqrt(dx * dx + dy * dy + dz * dz));
+  }
+  rg *= 1.0 + 0x1p-40;
+  float rf = (float)rg;
+  if ((double)rf < rg) rf = std::nextafterf(rf, HUGE_VALF);
+  G.rgeo = rf; // NaN / inf in, NaN / inf out: the group is then always a candidate
+  return G;
+}
+
 } // namespace esc
