@@ -1259,6 +1259,108 @@ DEVINL int anyhit_sph_pairs_filter(FetchF recf, FetchE rece, int n_rec, int base
 }
 
 // ---------------------------------------------------------------------------------------
+// Sphere GROUPS for shadow rays (rt_device.h SphGroups, last light only: any occluder decides the
+// ray, so the order of the tests is free).  The bounding sphere (C, R) of a group goes through the
+// same q' as a single sphere; R must hold every member's reach.  Member i not rejected at
+// `disc < 0` gives T(w_i) >= -(21.03u |w_i|^2 + u r_i^2 + 2^-149) (above; w_i = O - c_i), i.e. the
+// line's squared distance from c_i is |w_i|^2 - (w_i.L)^2 / |L|^2 <= r_i^2 (1+u) + 29.1u |w_i|^2 + 2^-149
+// (|L|^2 within 8u of 1) and its distance <= r_i (1+u) + 5.4 sqrt(u) |w_i| + 2^-74.  For a ray with
+// |fl(O - g)|_1 <= rho_max, |w_i| <= rho_max (1+u) + |C - g| + rgeo, so with rgeo >= r_i + |c_i - C|
+// the line passes C within
+//     R := rgeo + 0x1.6p-10 (rho_max + |C - g| + rgeo) + 2^-60      (5.4 * 2^-12 = 1.3184e-3 < 0x1.6p-10)
+// (host, double).  "Within R of C" is T_G(w) = (w.L)^2 - |w|^2 + R^2 >= (|w|^2 - R^2)(|L|^2 - 1) >=
+// -8u (|w|^2 + R^2): inside the hypothesis the single-sphere budget starts from (8 <= 21.03 on |w|^2;
+// 8u R^2 instead of u r^2 is covered by km's 255u R^2), so km built from (C, R^2) by the same formula
+// makes q'_G >= 0.  Rays that start further than rho_max from g (quirk S3 can do that) treat every
+// group as a candidate.
+// Returns the filter tests (groups + members of opened groups) this wave swept, for the
+// lane-efficiency counter; n_open counts the groups each ray itself needed opened.
+// ---------------------------------------------------------------------------------------
+constexpr int kGroupExitSteps = 16; // exit check every 128 groups
+template <typename FetchF, typename FetchE>
+DEVINL int anyhit_sph_groups_filter(FetchF recg, FetchF recf, FetchE rece, int n_grp, int base, f3 o,
+                                    f3 L, const RayF &rf, bool far, Any &a, int &n_open) {
+  int swept = 0;
+  const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
+  auto exact2 = [&](int k) { // sorted pair records k, k+1: the reference arithmetic
+    const PairG R[2] = {rece(k), rece(k + 1)};
+    v2f b[2], q[2];
+    pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                      __float_as_int(q[1].y));
+    if (!ANY_LANE_RARE(m >= 0)) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float t2;
+        if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2)) {
+          a.tocc = t2;
+          a.kocc = base + 2 * (k + i) + c; // position in the sorted table: never read (last light)
+          a.tb = 0.f;
+        }
+      }
+  };
+  auto members = [&](int g) { // the 8 spheres = 4 pair records of group g
+    PairF S[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[i] = recf(4 * g + i);
+    v2f q[4];
+    pair4_any_filter_pk(S, rf, q);
+    const int m01 = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                        __float_as_int(q[1].y));
+    const int m23 = max(max3i(__float_as_int(q[2].x), __float_as_int(q[2].y), __float_as_int(q[3].x)),
+                        __float_as_int(q[3].y));
+    if (ANY_LANE_RARE(max(m01, m23) >= 0)) {
+      if (__builtin_amdgcn_ballot_w64(m01 >= 0)) exact2(4 * g);
+      if (__builtin_amdgcn_ballot_w64(m23 >= 0)) exact2(4 * g + 2);
+    }
+  };
+  auto step = [&](const PairF(&G)[4], int g0) { // 8 groups
+    v2f q[4];
+    pair4_any_filter_pk(G, rf, q);
+    // a decided / dead lane (tb == 0) raises no flag here: its groups need not be opened
+    const bool live = a.tb > 0.f;
+    const int mm = max(max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                           __float_as_int(q[1].y)),
+                       max(max3i(__float_as_int(q[2].x), __float_as_int(q[2].y), __float_as_int(q[3].x)),
+                           __float_as_int(q[3].y)));
+    if (ANY_LANE_RARE(live && (far || mm >= 0))) {
+      uint32_t mask = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool c0 = live && (far || __float_as_int(q[j].x) >= 0);
+        const bool c1 = live && (far || __float_as_int(q[j].y) >= 0);
+        if (__builtin_amdgcn_ballot_w64(c0)) mask |= 1u << (2 * j);
+        if (__builtin_amdgcn_ballot_w64(c1)) mask |= 2u << (2 * j);
+        n_open += (int)c0 + (int)c1; // groups THIS ray needs opened (esc_counters.anyhit_tests)
+      }
+      while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        members(g0 + j);
+        swept += kSphGroup;
+      }
+    }
+  };
+  for (int s0 = 0; s0 < n_grp; s0 += 8 * kGroupExitSteps) {
+    if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return swept;
+    const int m = min(8 * kGroupExitSteps, n_grp - s0); // groups in this stretch, multiple of 8
+    swept += m;
+    PairF A[4], B[4];
+    fetch_batch(recg, s0 >> 1, A);
+    for (int g = 0; g < m; g += 16) {
+      fetch_batch(recg, recg.landed(A[3].k, (s0 + min(g + 8, m - 8)) >> 1), B);
+      step(A, s0 + g);
+      if (g + 8 >= m) break;
+      fetch_batch(recg, recg.landed(B[3].k, (s0 + min(g + 16, m - 8)) >> 1), A);
+      step(B, s0 + g + 8);
+    }
+  }
+  return swept;
+}
+
+// ---------------------------------------------------------------------------------------
 // re-packing of undecided shadow rays inside a workgroup
 //
 // A wave runs an any-hit loop until its LAST ray is decided, so rays that found their occluder
@@ -1275,6 +1377,7 @@ struct RepackLds {
   float tb[256];                   // bound; 0 = decided or never looking
   float tocc[256];
   int32_t kocc[256];
+  int32_t n_open[256]; // sphere groups opened for this ray (rt_device.h SphGroups; counters only)
   uint16_t list[256]; // packed position -> owning thread
   int32_t wave_cnt[4];
   // per-pixel shading state parked here while the any-hit segments run, so it does not hold

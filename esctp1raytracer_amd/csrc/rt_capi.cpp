@@ -546,8 +546,64 @@ int commit(esc_context *ctx, const Staged &s) {
                                     (int)std::min((size_t)esc::kSphGroup, order.size() - first));
     }
   }
+  // ... and the same groups for the last light's shadow rays: pair tables relative to g
+  std::vector<esc::DevSphPair> sg_sorted2(sg_sorted.size() / 2);
+  std::vector<esc::DevSphPairF> sg_sorted2f(sg_sorted.size() / 2), sg_grp2f(sg_grp.size() / 2);
+  {
+    auto filter_half = [&](esc::DevSphPairF &F, int h, double cx, double cy, double cz, double r2) {
+      const float c[3] = {(float)(cx - g[0]), (float)(cy - g[1]), (float)(cz - g[2])};
+      const double c2 = (double)c[0] * c[0] + (double)c[1] * c[1] + (double)c[2] * c[2];
+      const double km = r2 - c2 + 0x1p-16 * (c2 + std::fabs(r2)) + 0x1p-120;
+      float kf = (float)km;
+      if ((double)kf < km) kf = std::nextafterf(kf, __builtin_huge_valf());
+      F.cx[h] = c[0];
+      F.cy[h] = c[1];
+      F.cz[h] = c[2];
+      F.km[h] = kf; // NaN stays NaN: its bit pattern reads as a candidate
+    };
+    for (size_t k = 0; k < sg_sorted.size(); k++) {
+      const esc::DevSph &q = sg_sorted[k];
+      const size_t j = k >> 1;
+      const int h = (int)(k & 1);
+      sg_sorted2[j].cx[h] = q.cx;
+      sg_sorted2[j].cy[h] = q.cy;
+      sg_sorted2[j].cz[h] = q.cz;
+      sg_sorted2[j].r2[h] = q.r2; // pad: -inf, never hit
+      if (q.r2 == -__builtin_huge_valf()) {
+        sg_sorted2f[j].cx[h] = sg_sorted2f[j].cy[h] = sg_sorted2f[j].cz[h] = 0.f;
+        sg_sorted2f[j].km[h] = -__builtin_huge_valf();
+      } else {
+        filter_half(sg_sorted2f[j], h, q.cx, q.cy, q.cz, q.r2);
+      }
+    }
+    for (size_t k = 0; k < sg_grp.size(); k++) {
+      const esc::DevSphGroup &G = sg_grp[k];
+      const size_t j = k >> 1;
+      const int h = (int)(k & 1);
+      if (G.rgeo < 0.f) {
+        sg_grp2f[j].cx[h] = sg_grp2f[j].cy[h] = sg_grp2f[j].cz[h] = 0.f;
+        sg_grp2f[j].km[h] = -__builtin_huge_valf();
+        continue;
+      }
+      const double dx = (double)G.cx - g[0], dy = (double)G.cy - g[1], dz = (double)G.cz - g[2];
+      const double R = (double)G.rgeo +
+                       0x1.6p-10 * (rho + std::sqrt(dx * dx + dy * dy + dz * dz) + (double)G.rgeo) + 0x1p-60;
+      filter_half(sg_grp2f[j], h, G.cx, G.cy, G.cz, R * R * 1.00001);
+    }
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read old tables
   int rc;
+  {
+    esc::DevSphPair *d_s2 = const_cast<esc::DevSphPair *>(ctx->sg.sorted2);
+    esc::DevSphPairF *d_s2f = const_cast<esc::DevSphPairF *>(ctx->sg.sorted2_f);
+    esc::DevSphPairF *d_g2f = const_cast<esc::DevSphPairF *>(ctx->sg.grp2_f);
+    if ((rc = upload_vec(d_s2, sg_sorted2, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_s2f, sg_sorted2f, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_g2f, sg_grp2f, ctx->stream))) return rc;
+    ctx->sg.sorted2 = d_s2;
+    ctx->sg.sorted2_f = d_s2f;
+    ctx->sg.grp2_f = d_g2f;
+  }
   {
     esc::DevSph *d_sorted = const_cast<esc::DevSph *>(ctx->sg.sorted);
     esc::DevSphGroup *d_grp = const_cast<esc::DevSphGroup *>(ctx->sg.grp);
@@ -768,6 +824,9 @@ void esc_context_destroy(esc_context *ctx) {
                   ctx->d_tri2_f, const_cast<esc::DevSph *>(ctx->sg.sorted),
                   const_cast<esc::DevSphGroup *>(ctx->sg.grp), const_cast<esc::DevIdx4 *>(ctx->sg.orig),
                   ctx->sg.sorted_p, ctx->sg.sorted_f, ctx->sg.grp_f,
+                  const_cast<esc::DevSphPair *>(ctx->sg.sorted2),
+                  const_cast<esc::DevSphPairF *>(ctx->sg.sorted2_f),
+                  const_cast<esc::DevSphPairF *>(ctx->sg.grp2_f),
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits, ctx->d_sq, ctx->d_sq_ctl,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
@@ -1234,10 +1293,14 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   }();
   const int want = (opts->flags & ESC_RENDER_SHADE_QUEUE) ? 2
                    : (opts->flags & ESC_RENDER_SHADE_FUSED) ? 1 : shade_env;
+  // a single light's shadow rays sweep the sphere GROUPS in the fused form (rt_device.h SphGroups):
+  // about an eighth of the tests
+  const int64_t eff_sph =
+      (p.use_filter && p.sg.n_grp > 0 && p.n_lights == 1) ? p.n_sph / esc::kSphGroup : p.n_sph;
   const bool queue_form =
       stage == 1 && p.shadows && p.n_lights > 0 && want != 1 &&
       (want == 2 || opts->stage == ESC_STAGE_AUTO) &&
-      (want == 2 || ((int64_t)p.n_tri + p.n_sph >= kQueueMinPrims &&
+      (want == 2 || ((int64_t)p.n_tri + eff_sph >= kQueueMinPrims &&
                      (int64_t)n_local_rows * W >= kQueueMinPixels));
   if (queue_form) {
     int rc = render_shade_queue(ctx, p, px, timed ? ctx->ev[1] : nullptr);

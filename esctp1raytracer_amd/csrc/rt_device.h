@@ -105,6 +105,12 @@ struct SphGroups {
   DevSphP *sorted_p;         // per frame: DevSphP / DevSphF of `sorted`, DevSphF of `grp`
   DevSphF *sorted_f;
   DevSphF *grp_f;
+  // shadow rays of the LAST light (any occluder will do there, rt_device.h sph2_ord): the same
+  // sorted spheres and groups as pair tables, static per scene.  grp2_f holds the bounding spheres
+  // in DevSphPairF form with R = rgeo + 0x1.6p-10 (rho_max + |C - g| + rgeo) (rt_brute.h).
+  const DevSphPair *sorted2;    // n_grp * kSphGroup / 2 records
+  const DevSphPairF *sorted2_f; // same
+  const DevSphPairF *grp2_f;    // n_grp / 2 records (pad groups: km = -inf)
 };
 
 // Triangles (rt_brute.h "FILTERS", triangle part).  The reference's numerators are scalar triple

@@ -558,6 +558,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
   for (int li = 0; li < p.n_lights; ++li) {
     const DevLight Lt = p.lights[li];
     Any a[1];
+    int grp_open = -1; // >= 0: this light swept the sphere groups; groups opened for this ray
     f3 ro = N, rL = N; // shadow-ray origin (main.cpp:757 `hit`) and unit direction
     f3 lP = N;         // the light sample point and its index (light bins, ESC_STAGE_BVH)
     int lpt = 0;
@@ -626,13 +627,17 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         R.tb[tid] = a[0].tb;
         R.kocc[tid] = -1;
         R.tocc[tid] = 0.f;
+        R.n_open[tid] = 0;
         R.keep[0][tid] = N.x; R.keep[1][tid] = N.y; R.keep[2][tid] = N.z;
         R.keep[3][tid] = r; R.keep[4][tid] = g; R.keep[5][tid] = b;
         R.keep[6][tid] = t; R.keep[7][tid] = __int_as_float(mi);
         // Occluded rays mostly meet their occluder early in the list, so re-packing pays at
         // the beginning and not later: segment lengths double (256, 256, 512, 1024, ...
         // triangles; 512, 512, 1024, ... pair records), which keeps the barriers few.
-        const int n_rec = (p.n_sph + 1) >> 1;
+        // the last light sweeps the sphere GROUPS when the host built them (rt_device.h SphGroups):
+        // k0 then counts pair records of the sorted table, 4 per group, segments whole steps
+        const bool grp = (li == p.n_lights - 1) && p.use_filter && p.sg.n_grp > 0;
+        const int n_rec = grp ? p.sg.n_grp * (kSphGroup / 2) : (p.n_sph + 1) >> 1;
         int k0 = 0, seg = kSegTris; // triangles first (index order)
         bool in_tris = p.n_tri > 0;
         if (!in_tris) seg = kSegSphPairs;
@@ -671,6 +676,18 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
               } else {
                 anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri + k0}, n_here, k0, sov, sLv, aa);
               }
+            } else if (grp) {
+              const RayF rf = make_ray_filter(so, sL, p.shadow_center);
+              const float a1 = (fabsf(so.x - p.shadow_center[0]) + fabsf(so.y - p.shadow_center[1])) +
+                               fabsf(so.z - p.shadow_center[2]);
+              const bool far = !(a1 <= p.shadow_rho_max); // also catches NaN
+              int n_open = 0;
+              n_swept += anyhit_sph_groups_filter(
+                  SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (k0 >> 3)},
+                  SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.sorted2_f) + k0},
+                  SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2) + k0}, n_here >> 2,
+                  p.n_tri + 2 * k0, so, sL, rf, far, aa[0], n_open);
+              if (rr >= 0 && n_open) R.n_open[rr] += n_open;
             } else if (p.use_filter) {
               const RayF rf = make_ray_filter(so, sL, p.shadow_center);
               n_swept += 2 * anyhit_sph_pairs_filter(
@@ -694,6 +711,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         __syncthreads();
         a[0].kocc = R.kocc[tid];
         a[0].tocc = R.tocc[tid];
+        if (grp) grp_open = R.n_open[tid];
         rL = mk(R.lx[tid], R.ly[tid], R.lz[tid]); // not kept live across the segments
         N = mk(R.keep[0][tid], R.keep[1][tid], R.keep[2][tid]);
         r = R.keep[3][tid]; g = R.keep[4][tid]; b = R.keep[5][tid];
@@ -725,8 +743,16 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
       if (p.shadows) {
         n_shadow += 1u;
         // tests occlusion() runs for this ray: up to and including its first occluder
-        if (STAGE != STAGE_BVH)
-          n_any += (a[0].kocc >= 0) ? (unsigned)(a[0].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
+        if (STAGE != STAGE_BVH) {
+          if (grp_open >= 0 && !(a[0].kocc >= 0 && a[0].kocc < p.n_tri)) {
+            // group sweep: every triangle, the groups up to the occluder's (or all), 8 spheres per
+            // group this ray had opened
+            const int g_tested = (a[0].kocc >= 0) ? ((a[0].kocc - p.n_tri) >> 3) + 1 : p.sg.n_grp;
+            n_any += (unsigned)(p.n_tri + g_tested + kSphGroup * grp_open);
+          } else {
+            n_any += (a[0].kocc >= 0) ? (unsigned)(a[0].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
+          }
+        }
       }
       if (p.shadows && a[0].kocc >= 0) {
         t = a[0].tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
