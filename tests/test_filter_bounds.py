@@ -142,6 +142,171 @@ def test_shadow_filter_never_rejects_a_reference_candidate(scale, offset):
     assert (f32(fma(xr, xr, y) + km) >= 0).mean() < 0.25
 
 
+def _scaled_record(ocx, ocy, ocz, cc, r2a):
+    """k_prepare_*'s sphere_filter_record: (sx, sy, sz, w) of the scaled test |b''| >= 1"""
+    A = f32(f32(np.abs(ocx) + np.abs(ocy)) + np.abs(ocz))
+    ccm = f32(cc - f32(f32(f32(f32(A * A) + r2a) * f32(2.0 ** -19)) + f32(2.0 ** -120)))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sq = np.sqrt(np.maximum(ccm, f32(0)), dtype=f32)
+        s_eff = f32(f32(f32(sq * f32(1 - 2.0 ** -22)) - f32(A * f32(9 * 2.0 ** -24))) * f32(1 - 2.0 ** -22))
+        ok = (ccm > 0) & (s_eff > 0)
+        inv = f32(f32(1) / np.where(ok, s_eff, f32(1)))
+    z = f32(0)
+    return (np.where(ok, f32(ocx * inv), z), np.where(ok, f32(ocy * inv), z),
+            np.where(ok, f32(ocz * inv), z), np.where(ok, z, f32(2)))
+
+
+def _groups(rng, n_grp, scale, spread):
+    """n_grp groups of 8 spheres: centres within `spread` of a group point, radii 1e-3..1 x 0.2
+    scale; returns member centres/radii [n_grp, 8], and group_bounds()'s (C, rgeo) in fp32"""
+    gc = rng.uniform(-1, 1, (n_grp, 1, 3)) * scale
+    c = (gc + rng.normal(0, 1, (n_grp, 8, 3)) * spread).astype(f32)
+    r = (10.0 ** rng.uniform(-3, 0, (n_grp, 8)) * scale * 0.2).astype(f32)
+    r2 = f32(r * r)
+    rd = np.sqrt(r2.astype(np.float64))
+    lo = (c.astype(np.float64) - rd[..., None]).min(axis=1)
+    hi = (c.astype(np.float64) + rd[..., None]).max(axis=1)
+    C = (0.5 * (lo + hi)).astype(f32)
+    dist = np.linalg.norm(c.astype(np.float64) - C.astype(np.float64)[:, None, :], axis=2)
+    rg_d = (rd + dist).max(axis=1) * (1.0 + 2.0 ** -40)
+    rg = rg_d.astype(f32)
+    low = rg.astype(np.float64) < rg_d
+    rg[low] = np.nextafter(rg[low], f32(np.inf))
+    return c, r2, C, rg
+
+
+@pytest.mark.parametrize("scale,spread", [(1.0, 0.05), (30.0, 1.0), (1000.0, 5.0), (1000.0, 0.01)])
+def test_primary_group_filter_never_rejects_a_member_candidate(scale, spread):
+    """rt_device.h SphGroups, primary rays: k_prepare_groups' bounding-sphere record (R = rgeo +
+    0x1.2p-10 (A_G + 2 rgeo) + 2^-60) against the reference test of every member: a ray for which
+    ANY member is not rejected at `disc < 0` must have |b''_G| >= 1.  Rays graze a member's
+    silhouette; members reach from well inside the group to its rim, specks included."""
+    rng = np.random.default_rng(int(scale * 10 + spread * 1000))
+    n_grp = 200_000
+    c, r2, C, rg = _groups(rng, n_grp, scale, spread * scale / 30.0 if scale > 1 else spread)
+    o = (rng.uniform(-1, 1, (n_grp, 3)) * scale * 3).astype(f32)
+    k = rng.integers(0, 8, n_grp)
+    idx = np.arange(n_grp)
+    d = grazing_rays(rng, o, c[idx, k], np.sqrt(r2[idx, k]), n_grp)
+    # reference, every member (hoisted as k_prepare_groups does)
+    any_cand = np.zeros(n_grp, bool)
+    for m in range(8):
+        ocx, ocy, ocz = f32(o[:, 0] - c[:, m, 0]), f32(o[:, 1] - c[:, m, 1]), f32(o[:, 2] - c[:, m, 2])
+        cc = f32(ref_dot(ocx, ocy, ocz, ocx, ocy, ocz) - r2[:, m])
+        b = ref_dot(ocx, ocy, ocz, d[:, 0], d[:, 1], d[:, 2])
+        any_cand |= ~(f32(f32(b * b) - cc) < 0)
+    # group record
+    gx, gy, gz = f32(o[:, 0] - C[:, 0]), f32(o[:, 1] - C[:, 1]), f32(o[:, 2] - C[:, 2])
+    A = f32(f32(np.abs(gx) + np.abs(gy)) + np.abs(gz))
+    R = f32(f32(rg + f32(f32(1.125 * 2.0 ** -10) * f32(A + f32(f32(2) * rg)))) + f32(2.0 ** -60))
+    R2 = f32(f32(R * R) * f32(1.00001))
+    sx, sy, sz, w = _scaled_record(gx, gy, gz, f32(ref_dot(gx, gy, gz, gx, gy, gz) - R2), R2)
+    passed = np.abs(fma(sz, d[:, 2], fma(sy, d[:, 1], fma(sx, d[:, 0], w)))) >= 1
+    assert any_cand.sum() > n_grp // 4
+    missed = any_cand & ~passed
+    assert not missed.any(), f"{int(missed.sum())} member candidates behind a rejected group"
+    dr = unit(rng.normal(size=(n_grp, 3)))
+    assert (np.abs(fma(sz, dr[:, 2], fma(sy, dr[:, 1], fma(sx, dr[:, 0], w)))) >= 1).mean() < 0.5
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (30.0, 0.0), (30.0, 500.0), (1000.0, 0.0)])
+def test_shadow_group_filter_never_rejects_a_member_candidate(scale, offset):
+    """rt_device.h SphGroups, shadow rays of the last light: commit()'s bounding-sphere record in
+    DevSphPairF form (R = rgeo + 0x1.6p-10 (rho_max + |C - g| + rgeo) + 2^-60) against the reference's
+    16-op test of every member, for origins inside the scene box (|fl(O - g)|_1 <= rho_max)."""
+    rng = np.random.default_rng(11 + int(scale) + int(offset))
+    n_grp = 200_000
+    c, r2, C, rg = _groups(rng, n_grp, scale, 0.03 * scale)
+    c = (c.astype(np.float64) + offset).astype(f32)
+    C = (C.astype(np.float64) + offset).astype(f32)  # bounds stay valid up to fp32 rounding of
+    rg = f32(rg * f32(1.0 + 2.0 ** -20) + np.abs(C).max() * f32(2.0 ** -22))  # the shifted centres
+    o = (rng.uniform(-1, 1, (n_grp, 3)) * scale + offset).astype(f32)
+    k = rng.integers(0, 8, n_grp)
+    idx = np.arange(n_grp)
+    L = grazing_rays(rng, o, c[idx, k], np.sqrt(r2[idx, k]), n_grp)
+    any_cand = np.zeros(n_grp, bool)
+    for m in range(8):
+        ocx, ocy, ocz = f32(o[:, 0] - c[:, m, 0]), f32(o[:, 1] - c[:, m, 1]), f32(o[:, 2] - c[:, m, 2])
+        b = ref_dot(ocx, ocy, ocz, L[:, 0], L[:, 1], L[:, 2])
+        cc = f32(ref_dot(ocx, ocy, ocz, ocx, ocy, ocz) - r2[:, m])
+        any_cand |= ~(f32(f32(b * b) - cc) < 0)
+    # host side: g and rho_max as commit() takes them (box of everything, 1-norm radius doubled)
+    rd = np.sqrt(r2.astype(np.float64))
+    lo = np.minimum((c.astype(np.float64) - rd[..., None]).min(axis=(0, 1)), o.min(axis=0))
+    hi = np.maximum((c.astype(np.float64) + rd[..., None]).max(axis=(0, 1)), o.max(axis=0))
+    g = (0.5 * (lo + hi)).astype(f32)
+    rho = 2.0 * np.maximum(hi - g, g - lo).sum() + 1e-30
+    Cg = C.astype(np.float64) - g.astype(np.float64)
+    Rd = rg.astype(np.float64) + 1.375 * 2.0 ** -10 * (rho + np.linalg.norm(Cg, axis=1) + rg) + 2.0 ** -60
+    R2 = Rd * Rd * 1.00001
+    cp = Cg.astype(f32)
+    c2 = (cp.astype(np.float64) ** 2).sum(axis=1)
+    km_d = R2 - c2 + 2.0 ** -16 * (c2 + R2) + 2.0 ** -120
+    km = km_d.astype(f32)
+    low = km.astype(np.float64) < km_d
+    km[low] = np.nextafter(km[low], f32(np.inf))
+    ax, ay, az = f32(o[:, 0] - g[0]), f32(o[:, 1] - g[1]), f32(o[:, 2] - g[2])
+    assert (f32(f32(np.abs(ax) + np.abs(ay)) + np.abs(az)) <= f32(rho)).all()  # none is `far`
+    nn = ref_dot(ax, ay, az, ax, ay, az)
+    ss = ref_dot(ax, ay, az, L[:, 0], L[:, 1], L[:, 2])
+    nko = f32(nn * f32(-(1.0 - 2.0 ** -16)))
+    y = fma(cp[:, 2], f32(az + az), fma(cp[:, 1], f32(ay + ay), fma(cp[:, 0], f32(ax + ax), nko)))
+    x = fma(cp[:, 2], L[:, 2], fma(cp[:, 1], L[:, 1], fma(cp[:, 0], L[:, 0], f32(-ss))))
+    passed = f32(fma(x, x, y) + km) >= 0
+    assert any_cand.sum() > n_grp // 4
+    missed = any_cand & ~passed
+    assert not missed.any(), f"{int(missed.sum())} member candidates behind a rejected group"
+
+
+def test_group_slack_constants():
+    """the constants the proofs in rt_brute.h quote for the group radii"""
+    assert 1.125 * 2.0 ** -10 > (19.4 ** 0.5) * 2.0 ** -12 + 2.1 * U   # primary: 0x1.2p-10
+    assert 1.375 * 2.0 ** -10 > (29.1 ** 0.5) * 2.0 ** -12               # shadow:  0x1.6p-10
+    assert float.fromhex("0x1.2p-10") == 1.125 * 2.0 ** -10
+    assert float.fromhex("0x1.6p-10") == 1.375 * 2.0 ** -10
+
+
+@pytest.mark.parametrize("slack,expect_miss", [(1.125 * 2.0 ** -10, False), (0.0, True)])
+def test_primary_group_slack_is_what_specks_need(slack, expect_miss):
+    """Specks (r << sqrt(u) x distance): the reference's `disc < 0` is decided by rounding noise
+    and lets rays through that pass the speck at hundreds of radii.  A speck on the rim of its
+    group, the ray passing on the far side: the group radius must reach rgeo + that noise.  With
+    the documented slack no member candidate is lost, without it some are -- the experiment has
+    the power to see a missing term."""
+    rng = np.random.default_rng(99)
+    n = 400_000
+    C = (rng.uniform(-1, 1, (n, 3)) * 100).astype(np.float64)
+    o = (C + unit(rng.normal(size=(n, 3))) * 10.0 ** rng.uniform(1.5, 3, (n, 1))).astype(f32)
+    dist = np.linalg.norm(o.astype(np.float64) - C, axis=1, keepdims=True)
+    w = (C - o) / dist
+    e = rng.normal(size=(n, 3))
+    e -= (e * w).sum(axis=1, keepdims=True) * w
+    e /= np.linalg.norm(e, axis=1, keepdims=True)            # across the line of sight
+    half = dist * 10.0 ** rng.uniform(-3.0, -1.5, (n, 1))     # group half-width: the noise reach and up
+    c1 = (C + e * half).astype(f32)                           # the speck on the rim ...
+    c2 = (C - e * half).astype(f32)                           # ... and its opposite number
+    r2 = f32(1e-10)
+    Cf = (0.5 * (np.minimum(c1, c2).astype(np.float64) - 1e-5 + np.maximum(c1, c2).astype(np.float64) + 1e-5)).astype(f32)
+    rg_d = np.maximum(np.linalg.norm(c1.astype(np.float64) - Cf, axis=1),
+                      np.linalg.norm(c2.astype(np.float64) - Cf, axis=1)) + 1e-5
+    rg = (rg_d * (1 + 2.0 ** -40)).astype(f32)
+    rg = np.where(rg.astype(np.float64) < rg_d, np.nextafter(rg, f32(np.inf)), rg)
+    D = dist * rng.uniform(0, 8e-4, (n, 1))                   # beyond the speck, outward
+    d = unit(c1.astype(np.float64) + e * D - o)
+    ocx, ocy, ocz = f32(o[:, 0] - c1[:, 0]), f32(o[:, 1] - c1[:, 1]), f32(o[:, 2] - c1[:, 2])
+    cc = f32(ref_dot(ocx, ocy, ocz, ocx, ocy, ocz) - r2)
+    b = ref_dot(ocx, ocy, ocz, d[:, 0], d[:, 1], d[:, 2])
+    cand = ~(f32(f32(b * b) - cc) < 0)
+    gx, gy, gz = f32(o[:, 0] - Cf[:, 0]), f32(o[:, 1] - Cf[:, 1]), f32(o[:, 2] - Cf[:, 2])
+    A = f32(f32(np.abs(gx) + np.abs(gy)) + np.abs(gz))
+    R = f32(f32(rg + f32(f32(slack) * f32(A + f32(f32(2) * rg)))) + f32(2.0 ** -60))
+    R2 = f32(f32(R * R) * f32(1.00001))
+    sx, sy, sz, w4 = _scaled_record(gx, gy, gz, f32(ref_dot(gx, gy, gz, gx, gy, gz) - R2), R2)
+    passed = np.abs(fma(sz, d[:, 2], fma(sy, d[:, 1], fma(sx, d[:, 0], w4)))) >= 1
+    assert cand.sum() > n // 20 and (~cand).sum() > n // 20
+    assert bool((cand & ~passed).any()) == expect_miss
+
+
 def test_filter_margins_match_the_documented_budget():
     """the constants the proof in rt_brute.h quotes: provided margins exceed the needed ones"""
     assert 32 * U == 2.0 ** -19 and 256 * U == 2.0 ** -16

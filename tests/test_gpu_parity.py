@@ -305,6 +305,69 @@ def test_filter_adversarial_scenes_vs_oracle(esc, renderer, case):
         assert ref.sum() > 0
 
 
+@pytest.mark.parametrize("case", ["equal t: duplicated spheres", "tight clusters far apart",
+                                  "camera between the members of a group", "far specks",
+                                  "one group and a bit", "collinear centres"])
+def test_sphere_groups_vs_oracle(esc, renderer, case):
+    """From 64 spheres up the brute-force kernels test bounding spheres of k-d ordered runs of 8
+    spheres first (csrc/rt_device.h SphGroups).  Scenes against what that adds: hits at EQUAL t on
+    spheres with different indices and materials (the reference keeps the lower index; the groups
+    are not swept in index order), groups whose bounding sphere holds the camera, specks whose
+    accepts are rounding noise, partly filled last groups, degenerate splits.  Frame == oracle bit
+    for bit with 1, 2 and 3 lights, 1 and 2 pixels per lane; == index order == exact-only."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    eye, look = np.array([0.0, 1.0, 6.0]), np.array([0.0, 1.0, 0.0])
+    n = 200
+    c = np.concatenate([rng.uniform(-3, 3, (n, 1)), rng.uniform(0.2, 3.5, (n, 1)),
+                        rng.uniform(-4, 2, (n, 1))], axis=1)
+    r = rng.uniform(0.05, 0.4, n)
+    if case == "equal t: duplicated spheres":
+        c, r = np.concatenate([c[:70]] * 3), np.concatenate([r[:70]] * 3)  # 3 copies, 3 materials
+        perm = rng.permutation(len(r))
+        c, r = c[perm], r[perm]
+    elif case == "tight clusters far apart":
+        centres = rng.uniform(-1, 1, (25, 3)) * (40, 15, 40) + (0, 16, -45)
+        c = (centres[:, None, :] + rng.normal(0, 0.3, (25, 8, 3))).reshape(-1, 3)
+        r = rng.uniform(0.1, 0.5, len(c))
+    elif case == "camera between the members of a group":
+        v = rng.normal(0, 1, (16, 3))
+        c[:16] = eye + v / np.linalg.norm(v, axis=1)[:, None] * 0.8  # a shell around the camera
+        r[:16] = 0.2
+    elif case == "far specks":
+        c[:120] = rng.uniform(-1, 1, (120, 3)) * (300, 100, 50) + (0, 100, -900)
+        r[:120] = 10.0 ** rng.uniform(-4, -1, 120)
+    elif case == "one group and a bit":
+        c, r = c[:67], r[:67]
+    elif case == "collinear centres":
+        k = np.arange(n)
+        c = np.stack([k * 0.03 - 3.0, np.full(n, 1.0), np.full(n, -1.0)], axis=1)
+        r = np.full(n, 0.1)
+    n = len(r)
+    fl = np.array([[-6, 0, 4], [6, 0, 4], [6, 0, -8], [-6, 0, -8]], float)
+    l1 = np.array([[-0.3, 7, -1], [0.3, 7, -1], [0, 7, -1.6]], float)
+    l2 = np.array([[4, 5, 2], [4.4, 5, 2], [4, 5.4, 2.2]], float)
+    l3 = np.array([[-5, 3, 3], [-5, 3.3, 3], [-4.8, 3, 3.3]], float)
+    sph = np.concatenate([c, r[:, None]], axis=1).astype(np.float32)
+    mats = np.stack([ol.material13(ka=m, kd=m) for m in rng.uniform(0.2, 0.9, (n, 3))])
+    for lights in ([l1], [l1, l2], [l1, l2, l3]):
+        geoms = [{"vertex": fl[[0, 1, 2, 0, 2, 3]].astype(np.float32),
+                  "face_index": np.arange(6).reshape(2, 3), "material": ol.WHITE}]
+        for lt in lights:
+            geoms.append({"vertex": lt.astype(np.float32), "face_index": np.array([[0, 1, 2]]),
+                          "material": ol.LIGHT_A})
+        d = ol.scene_dict(geoms, sph, mats)
+        W, H = 224, 128
+        for px in (1, 2):
+            gpu, u8, ref = render_both(esc, renderer, d, tuple(eye), tuple(look), W, H, px=px)
+            assert_bit_equal(gpu, ref, f"groups/{case}/{len(lights)} lights/px{px}")
+        cam = esc.Camera.for_image(tuple(eye), tuple(look), W, H)
+        for flags in (esc.ESC_RENDER_INDEX_ORDER, esc.ESC_RENDER_EXACT_ONLY,
+                      esc.ESC_RENDER_SHADE_QUEUE):
+            other = renderer.render(cam, W, H, flags=flags)
+            assert_bit_equal(other, ref, f"groups/{case}/{len(lights)} lights/flags{flags}")
+        assert ref.sum() > 0
+
+
 @pytest.mark.parametrize("form", ["queue", "fused"])
 def test_both_shading_forms_on_small_frames(esc, renderer, form):
     """The queue form is chosen by default only for long primitive lists on large bands; force
