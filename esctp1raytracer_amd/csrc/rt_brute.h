@@ -478,61 +478,76 @@ DEVINL void test_sph_primary_sorted(const DevSphP (&s)[4], const DevIdx4 &orig, 
   }
 }
 
-// n_grp is a multiple of kSphGroupStep (= 8, pad groups never pass); group g's members are the
-// sorted slots [8 g, 8 g + 8).
+// the scaled test on 8 records x 2 pixels: wave-uniform mask of the records SOME lane passes
+// (0 for nearly every step: the per-record ballots sit behind one wave-wide check)
+DEVINL uint32_t sph8_primary_mask(const SphF2 (&S)[8], const V3<v2f> &d) {
+  v2f q0[4], q1[4];
+  const SphF2(&S0)[4] = reinterpret_cast<const SphF2(&)[4]>(S[0]);
+  const SphF2(&S1)[4] = reinterpret_cast<const SphF2(&)[4]>(S[4]);
+  sph4_primary_filter_pk(S0, d.x, d.y, d.z, q0);
+  sph4_primary_filter_pk(S1, d.x, d.y, d.z, q1);
+  const float m = max_abs8(q1, max_abs8(q0, 0.f));
+  uint32_t mask = 0;
+  if (ANY_LANE_RARE(m >= 1.f)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const v2f q = j < 4 ? q0[j & 3] : q1[j & 3];
+      if (__builtin_amdgcn_ballot_w64(fmaxf(fabsf(q.x), fabsf(q.y)) >= 1.f) != 0) mask |= 1u << j;
+    }
+  }
+  return mask;
+}
+
+// Two-level sweep (rt_device.h SphGroups): 8 super-groups per step, double-buffered; an opened
+// super-group costs one step over its 8 groups, an opened group one over its 8 spheres' filter
+// records, and only spheres that pass that run the reference arithmetic.  Super-group s holds
+// groups [8 s, 8 s + 8), group g the sorted slots [8 g, 8 g + 8); n_sup is a multiple of 8 (pad
+// records never pass).
 template <typename FetchF, typename FetchE, typename FetchI>
-DEVINL void closest_sph_primary_groups(FetchF recg, FetchF recf, FetchE rece, FetchI reci, int n_grp,
-                                       int base, const V3<v2f> &d, Hit (&h)[2]) {
-  static_assert(kSphGroup == 8 && kSphGroupStep == 8, "8 x 8 bodies below");
+DEVINL void closest_sph_primary_groups(FetchF recu, FetchF recg, FetchF recf, FetchE rece, FetchI reci,
+                                       int n_sup, int base, const V3<v2f> &d, Hit (&h)[2]) {
+  static_assert(kSphGroup == 8 && kSphSuper == 8 && kSphGroupStep == 8, "8-wide bodies below");
   auto members = [&](int g) {
     SphF2 S[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) S[i] = recf(8 * g + i);
-    v2f q0[4], q1[4];
-    const SphF2(&S0)[4] = reinterpret_cast<const SphF2(&)[4]>(S[0]);
-    const SphF2(&S1)[4] = reinterpret_cast<const SphF2(&)[4]>(S[4]);
-    sph4_primary_filter_pk(S0, d.x, d.y, d.z, q0);
-    sph4_primary_filter_pk(S1, d.x, d.y, d.z, q1);
-    const float m = max_abs8(q1, max_abs8(q0, 0.f));
-    if (ANY_LANE_RARE(m >= 1.f)) {
+    const uint32_t mask = sph8_primary_mask(S, d);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2; ++j)
+      if (mask & (0xFu << (4 * j))) {
         DevSphP E[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) E[i] = rece(8 * g + 4 * j + i);
         test_sph_primary_sorted(E, reci(2 * g + j), base, d, h);
       }
+  };
+  auto groups = [&](int s) {
+    SphF2 G[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) G[i] = recg(8 * s + i);
+    uint32_t mask = sph8_primary_mask(G, d);
+    while (mask) {
+      const int j = __builtin_ctz(mask);
+      mask &= mask - 1;
+      members(8 * s + j);
     }
   };
-  auto step = [&](const SphF2(&G)[8], int g0) {
-    v2f q0[4], q1[4];
-    const SphF2(&G0)[4] = reinterpret_cast<const SphF2(&)[4]>(G[0]);
-    const SphF2(&G1)[4] = reinterpret_cast<const SphF2(&)[4]>(G[4]);
-    sph4_primary_filter_pk(G0, d.x, d.y, d.z, q0);
-    sph4_primary_filter_pk(G1, d.x, d.y, d.z, q1);
-    const float m = max_abs8(q1, max_abs8(q0, 0.f));
-    if (ANY_LANE_RARE(m >= 1.f)) {
-      uint32_t mask = 0; // wave-uniform: which of the 8 groups
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const v2f q = j < 4 ? q0[j & 3] : q1[j & 3];
-        if (__builtin_amdgcn_ballot_w64(fmaxf(fabsf(q.x), fabsf(q.y)) >= 1.f) != 0) mask |= 1u << j;
-      }
-      while (mask) {
-        const int j = __builtin_ctz(mask);
-        mask &= mask - 1;
-        members(g0 + j);
-      }
+  auto step = [&](const SphF2(&U)[8], int s0) {
+    uint32_t mask = sph8_primary_mask(U, d);
+    while (mask) {
+      const int j = __builtin_ctz(mask);
+      mask &= mask - 1;
+      groups(s0 + j);
     }
   };
   SphF2 A[8], B[8];
-  fetch_batch(recg, 0, A);
-  for (int g = 0; g < n_grp; g += 16) {
-    fetch_batch(recg, recg.landed(A[7].yz, min(g + 8, n_grp - 8)), B);
-    step(A, g);
-    if (g + 8 >= n_grp) break; // odd number of steps: B was a clamped refetch, unused
-    fetch_batch(recg, recg.landed(B[7].yz, min(g + 16, n_grp - 8)), A);
-    step(B, g + 8);
+  fetch_batch(recu, 0, A);
+  for (int s = 0; s < n_sup; s += 16) {
+    fetch_batch(recu, recu.landed(A[7].yz, min(s + 8, n_sup - 8)), B);
+    step(A, s);
+    if (s + 8 >= n_sup) break; // odd number of steps: B was a clamped refetch, unused
+    fetch_batch(recu, recu.landed(B[7].yz, min(s + 16, n_sup - 8)), A);
+    step(B, s + 8);
   }
 }
 
@@ -1273,13 +1288,16 @@ DEVINL int anyhit_sph_pairs_filter(FetchF recf, FetchE rece, int n_rec, int base
 // 8u R^2 instead of u r^2 is covered by km's 255u R^2), so km built from (C, R^2) by the same formula
 // makes q'_G >= 0.  Rays that start further than rho_max from g (quirk S3 can do that) treat every
 // group as a candidate.
-// Returns the filter tests (groups + members of opened groups) this wave swept, for the
-// lane-efficiency counter; n_open counts the groups each ray itself needed opened.
+// Two levels, as for primary rays: 8 super-groups per step, an opened super-group costs one step
+// over its 8 groups, an opened group one over its 8 spheres.
+// Returns the filter tests (8 per step, at any level) this wave swept, for the lane-efficiency
+// counter; n_open counts the 8-record openings each ray itself needed.
 // ---------------------------------------------------------------------------------------
-constexpr int kGroupExitSteps = 16; // exit check every 128 groups
+constexpr int kGroupExitSteps = 2; // exit check every 16 super-groups
 template <typename FetchF, typename FetchE>
-DEVINL int anyhit_sph_groups_filter(FetchF recg, FetchF recf, FetchE rece, int n_grp, int base, f3 o,
-                                    f3 L, const RayF &rf, bool far, Any &a, int &n_open) {
+DEVINL int anyhit_sph_groups_filter(FetchF recu, FetchF recg, FetchF recf, FetchE rece, int n_sup,
+                                    int base, f3 o, f3 L, const RayF &rf, bool far, Any &a,
+                                    int &n_open) {
   int swept = 0;
   const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
   auto exact2 = [&](int k) { // sorted pair records k, k+1: the reference arithmetic
@@ -1311,49 +1329,66 @@ DEVINL int anyhit_sph_groups_filter(FetchF recg, FetchF recf, FetchE rece, int n
                         __float_as_int(q[1].y));
     const int m23 = max(max3i(__float_as_int(q[2].x), __float_as_int(q[2].y), __float_as_int(q[3].x)),
                         __float_as_int(q[3].y));
+    // a decided / dead lane (tb == 0) may still raise the flag; the exact code accepts nothing for it
     if (ANY_LANE_RARE(max(m01, m23) >= 0)) {
       if (__builtin_amdgcn_ballot_w64(m01 >= 0)) exact2(4 * g);
       if (__builtin_amdgcn_ballot_w64(m23 >= 0)) exact2(4 * g + 2);
     }
   };
-  auto step = [&](const PairF(&G)[4], int g0) { // 8 groups
+  // 4 pair records = 8 bounding spheres: wave-uniform mask of the ones some LIVE lane may touch
+  auto open_mask = [&](const PairF(&G)[4]) -> uint32_t {
     v2f q[4];
     pair4_any_filter_pk(G, rf, q);
-    // a decided / dead lane (tb == 0) raises no flag here: its groups need not be opened
     const bool live = a.tb > 0.f;
     const int mm = max(max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
                            __float_as_int(q[1].y)),
                        max(max3i(__float_as_int(q[2].x), __float_as_int(q[2].y), __float_as_int(q[3].x)),
                            __float_as_int(q[3].y)));
+    uint32_t mask = 0;
     if (ANY_LANE_RARE(live && (far || mm >= 0))) {
-      uint32_t mask = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool c0 = live && (far || __float_as_int(q[j].x) >= 0);
         const bool c1 = live && (far || __float_as_int(q[j].y) >= 0);
         if (__builtin_amdgcn_ballot_w64(c0)) mask |= 1u << (2 * j);
         if (__builtin_amdgcn_ballot_w64(c1)) mask |= 2u << (2 * j);
-        n_open += (int)c0 + (int)c1; // groups THIS ray needs opened (esc_counters.anyhit_tests)
-      }
-      while (mask) {
-        const int j = __builtin_ctz(mask);
-        mask &= mask - 1;
-        members(g0 + j);
-        swept += kSphGroup;
+        n_open += (int)c0 + (int)c1; // openings THIS ray needs (esc_counters.anyhit_tests)
       }
     }
+    return mask;
   };
-  for (int s0 = 0; s0 < n_grp; s0 += 8 * kGroupExitSteps) {
+  auto groups = [&](int s) { // the 8 groups = 4 pair records of super-group s
+    PairF G[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) G[i] = recg(4 * s + i);
+    uint32_t mask = open_mask(G);
+    while (mask) {
+      const int j = __builtin_ctz(mask);
+      mask &= mask - 1;
+      members(8 * s + j);
+      swept += kSphGroup;
+    }
+  };
+  auto step = [&](const PairF(&U)[4], int s0) { // 8 super-groups
+    uint32_t mask = open_mask(U);
+    while (mask) {
+      const int j = __builtin_ctz(mask);
+      mask &= mask - 1;
+      groups(s0 + j);
+      swept += kSphSuper;
+    }
+  };
+  for (int s0 = 0; s0 < n_sup; s0 += 8 * kGroupExitSteps) {
     if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return swept;
-    const int m = min(8 * kGroupExitSteps, n_grp - s0); // groups in this stretch, multiple of 8
+    const int m = min(8 * kGroupExitSteps, n_sup - s0); // super-groups in this stretch, multiple of 8
     swept += m;
     PairF A[4], B[4];
-    fetch_batch(recg, s0 >> 1, A);
+    fetch_batch(recu, s0 >> 1, A);
     for (int g = 0; g < m; g += 16) {
-      fetch_batch(recg, recg.landed(A[3].k, (s0 + min(g + 8, m - 8)) >> 1), B);
+      fetch_batch(recu, recu.landed(A[3].k, (s0 + min(g + 8, m - 8)) >> 1), B);
       step(A, s0 + g);
       if (g + 8 >= m) break;
-      fetch_batch(recg, recg.landed(B[3].k, (s0 + min(g + 16, m - 8)) >> 1), A);
+      fetch_batch(recu, recu.landed(B[3].k, (s0 + min(g + 16, m - 8)) >> 1), A);
       step(B, s0 + g + 8);
     }
   }
@@ -1387,6 +1422,10 @@ struct RepackLds {
 };
 constexpr int kSegTris = 256;     // primitives per segment between re-packs
 constexpr int kSegSphPairs = 512; // = 1024 spheres
+// group sweeps (rt_device.h SphGroups) are short enough that re-packing between segments only
+// costs (c4, first segment 256 / 1024 / 4096 records / one segment: shading 0.576 / 0.555 / 0.526 /
+// 0.504 ms): one segment up to 2^20 pair records, whole steps of 8 super-groups (256 records)
+constexpr int kSegGroupPairs = 1 << 20;
 
 // all 256 threads; returns the number of rays still looking (workgroup-uniform)
 DEVINL int repack_rays(RepackLds &R, int tid) {

@@ -520,11 +520,15 @@ int commit(esc_context *ctx, const Staged &s) {
   std::vector<esc::DevSph> sg_sorted;
   std::vector<esc::DevSphGroup> sg_grp;
   std::vector<esc::DevIdx4> sg_orig;
+  size_t sg_n_grp = 0;
   if ((int)s.sph.size() >= esc::kSphGroupMinSpheres) {
     std::vector<int32_t> order;
-    esc::group_order(s.sph, esc::kSphGroup, order);
+    constexpr size_t kBig = (size_t)esc::kSphGroup * esc::kSphSuper; // spheres per super-group
+    esc::group_order(s.sph, esc::kSphGroup, (int)kBig, order);
     const size_t n_real = (s.sph.size() + esc::kSphGroup - 1) / esc::kSphGroup;
-    const size_t n_grp = (n_real + esc::kSphGroupStep - 1) / esc::kSphGroupStep * esc::kSphGroupStep;
+    const size_t n_sup_real = (s.sph.size() + kBig - 1) / kBig;
+    const size_t n_sup = (n_sup_real + esc::kSphGroupStep - 1) / esc::kSphGroupStep * esc::kSphGroupStep;
+    const size_t n_grp = n_sup * esc::kSphSuper;
     esc::DevSph pad_s;
     pad_s.cx = pad_s.cy = pad_s.cz = 0.f;
     pad_s.r2 = -__builtin_huge_valf();
@@ -532,7 +536,7 @@ int commit(esc_context *ctx, const Staged &s) {
     esc::DevSphGroup pad_g;
     pad_g.cx = pad_g.cy = pad_g.cz = 0.f;
     pad_g.rgeo = -1.f;
-    sg_grp.assign(n_grp, pad_g);
+    sg_grp.assign(n_grp + n_sup, pad_g); // groups, then super-groups
     esc::DevIdx4 pad_i;
     pad_i.v[0] = pad_i.v[1] = pad_i.v[2] = pad_i.v[3] = INT32_MAX / 2;
     sg_orig.assign(n_grp * esc::kSphGroup / 4, pad_i);
@@ -545,6 +549,12 @@ int commit(esc_context *ctx, const Staged &s) {
       sg_grp[j] = esc::group_bounds(s.sph, order.data() + first,
                                     (int)std::min((size_t)esc::kSphGroup, order.size() - first));
     }
+    for (size_t j = 0; j < n_sup_real; j++) {
+      const size_t first = j * kBig;
+      sg_grp[n_grp + j] =
+          esc::group_bounds(s.sph, order.data() + first, (int)std::min(kBig, order.size() - first));
+    }
+    sg_n_grp = n_grp;
   }
   // ... and the same groups for the last light's shadow rays: pair tables relative to g
   std::vector<esc::DevSphPair> sg_sorted2(sg_sorted.size() / 2);
@@ -617,7 +627,8 @@ int commit(esc_context *ctx, const Staged &s) {
     if ((rc = alloc_dev(ctx->sg.sorted_p, sg_sorted.size()))) return rc;
     if ((rc = alloc_dev(ctx->sg.sorted_f, sg_sorted.size()))) return rc;
     if ((rc = alloc_dev(ctx->sg.grp_f, sg_grp.size()))) return rc;
-    ctx->sg.n_grp = (int32_t)sg_grp.size();
+    ctx->sg.n_grp = (int32_t)sg_n_grp;
+    ctx->sg.n_sup = (int32_t)(sg_grp.size() - sg_n_grp);
   }
   if ((rc = upload_vec(ctx->d_sph2_ord, sph2o, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph2_f_ord, sph2fo, ctx->stream))) return rc;
@@ -1165,7 +1176,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       return e && std::strcmp(e, "0") == 0;
     }();
     p.sg = ctx->sg;
-    if (index_order || env_nogroups) p.sg.n_grp = 0;
+    if (index_order || env_nogroups) p.sg.n_grp = p.sg.n_sup = 0;
+
   }
   p.tri_f = ctx->d_tri_f;
   p.tri_pf = ctx->d_tri_pf;

@@ -89,7 +89,8 @@ struct alignas(16) DevSphPairF {
 // the image.
 // ---------------------------------------------------------------------------------------
 constexpr int kSphGroup = 8;          // spheres per group
-constexpr int kSphGroupStep = 8;      // groups per sweep step: n_grp is a multiple of this
+constexpr int kSphSuper = 8;          // groups per super-group (the level the sweeps start at)
+constexpr int kSphGroupStep = 8;      // super-groups per sweep step: n_sup is a multiple of this
 constexpr int kSphGroupMinSpheres = 64;
 struct alignas(16) DevSphGroup { // static: centre and the radius that holds every member sphere
   float cx, cy, cz, rgeo;        // pad group: rgeo < 0
@@ -97,20 +98,25 @@ struct alignas(16) DevSphGroup { // static: centre and the radius that holds eve
 struct alignas(16) DevIdx4 {
   int32_t v[4];
 };
+// Two levels: kSphSuper consecutive groups (64 spheres, one subtree of the k-d order) form a
+// super-group with its own bounding sphere, same record forms.  A sweep tests 8 super-groups per
+// step, opens the ones some ray of the wave may touch (one step over their 8 groups), and opens
+// groups from there.
 struct SphGroups {
-  int32_t n_grp, pad;        // 0: no groups (small scenes, ESC_RENDER_INDEX_ORDER, filters off)
+  int32_t n_grp, n_sup;      // n_grp = 8 n_sup; 0: no groups (small scenes, ESC_RENDER_INDEX_ORDER,
+                             // filters off)
   const DevSph *sorted;      // n_grp * kSphGroup spheres in group order; pad slots have r2 = -inf
-  const DevSphGroup *grp;    // n_grp
+  const DevSphGroup *grp;    // n_grp, then the n_sup super-groups
   const DevIdx4 *orig;       // original index of each sorted slot, 4 per record; pads INT32_MAX / 2
   DevSphP *sorted_p;         // per frame: DevSphP / DevSphF of `sorted`, DevSphF of `grp`
   DevSphF *sorted_f;
-  DevSphF *grp_f;
+  DevSphF *grp_f;            // n_grp + n_sup
   // shadow rays of the LAST light (any occluder will do there, rt_device.h sph2_ord): the same
   // sorted spheres and groups as pair tables, static per scene.  grp2_f holds the bounding spheres
   // in DevSphPairF form with R = rgeo + 0x1.6p-10 (rho_max + |C - g| + rgeo) (rt_brute.h).
   const DevSphPair *sorted2;    // n_grp * kSphGroup / 2 records
   const DevSphPairF *sorted2_f; // same
-  const DevSphPairF *grp2_f;    // n_grp / 2 records (pad groups: km = -inf)
+  const DevSphPairF *grp2_f;    // n_grp / 2 records (pad groups: km = -inf), then n_sup / 2
 };
 
 // Triangles (rt_brute.h "FILTERS", triangle part).  The reference's numerators are scalar triple

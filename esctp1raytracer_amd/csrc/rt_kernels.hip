@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) k_prepare_groups(const SphGroups g, float
     g.sorted_p[i] = P;
     g.sorted_f[i] = F;
   }
-  if (i < g.n_grp) {
+  if (i < g.n_grp + g.n_sup) { // groups, then super-groups: same form
     const DevSphGroup G = g.grp[i];
     DevSphF F;
     F.sx = F.sy = F.sz = F.w = 0.f; // pad group: never a candidate
@@ -416,10 +416,12 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     if constexpr (PX == 2) {
       // multiples of 8 through the hand-scheduled packed bodies, the tail through the generic one
       if (p.use_filter && p.sg.n_grp > 0) {
-        closest_sph_primary_groups(SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f)},
-                                   SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.sorted_f)},
-                                   SmemFetch<DevSphP>{p.sg.sorted_p}, SmemFetch<DevIdx4>{p.sg.orig},
-                                   p.sg.n_grp, p.n_tri, dv[0], hit);
+        closest_sph_primary_groups(
+            SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp},
+            SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f)},
+            SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.sorted_f)},
+            SmemFetch<DevSphP>{p.sg.sorted_p}, SmemFetch<DevIdx4>{p.sg.orig}, p.sg.n_sup, p.n_tri,
+            dv[0], hit);
       } else {
       const int n8 = p.n_sph & ~7;
       if (p.use_filter)
@@ -640,12 +642,13 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         const int n_rec = grp ? p.sg.n_grp * (kSphGroup / 2) : (p.n_sph + 1) >> 1;
         int k0 = 0, seg = kSegTris; // triangles first (index order)
         bool in_tris = p.n_tri > 0;
-        if (!in_tris) seg = kSegSphPairs;
+        const int seg_sph = grp ? kSegGroupPairs : kSegSphPairs;
+        if (!in_tris) seg = seg_sph;
         for (int sg = 0;; ++sg) {
           if (in_tris && k0 >= p.n_tri) {
             in_tris = false;
             k0 = 0;
-            seg = kSegSphPairs;
+            seg = seg_sph;
             sg = 0;
           }
           if (!in_tris && k0 >= n_rec) break;
@@ -682,10 +685,12 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
                                fabsf(so.z - p.shadow_center[2]);
               const bool far = !(a1 <= p.shadow_rho_max); // also catches NaN
               int n_open = 0;
+              // k0 pair records in = k0 / 4 groups = k0 / 32 super-groups; two per record
               n_swept += anyhit_sph_groups_filter(
+                  SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (p.sg.n_grp >> 1) + (k0 >> 6)},
                   SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (k0 >> 3)},
                   SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.sorted2_f) + k0},
-                  SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2) + k0}, n_here >> 2,
+                  SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2) + k0}, n_here >> 5,
                   p.n_tri + 2 * k0, so, sL, rf, far, aa[0], n_open);
               if (rr >= 0 && n_open) R.n_open[rr] += n_open;
             } else if (p.use_filter) {
@@ -706,7 +711,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
             }
           }
           k0 += n_here;
-          if (sg >= 1) seg *= 2;
+          if (sg >= 1 && seg < (1 << 29)) seg *= 2;
         }
         __syncthreads();
         a[0].kocc = R.kocc[tid];
@@ -745,10 +750,10 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         // tests occlusion() runs for this ray: up to and including its first occluder
         if (STAGE != STAGE_BVH) {
           if (grp_open >= 0 && !(a[0].kocc >= 0 && a[0].kocc < p.n_tri)) {
-            // group sweep: every triangle, the groups up to the occluder's (or all), 8 spheres per
-            // group this ray had opened
-            const int g_tested = (a[0].kocc >= 0) ? ((a[0].kocc - p.n_tri) >> 3) + 1 : p.sg.n_grp;
-            n_any += (unsigned)(p.n_tri + g_tested + kSphGroup * grp_open);
+            // group sweep: every triangle, the super-groups up to the occluder's (or all), 8 more
+            // filter tests per super-group / group this ray had opened
+            const int s_tested = (a[0].kocc >= 0) ? ((a[0].kocc - p.n_tri) >> 6) + 1 : p.sg.n_sup;
+            n_any += (unsigned)(p.n_tri + s_tested + 8 * grp_open);
           } else {
             n_any += (a[0].kocc >= 0) ? (unsigned)(a[0].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
           }

@@ -489,15 +489,17 @@ void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, 
 }
 
 // ---- sphere groups of the brute-force primary pass (rt_device.h SphGroups) ----------------
-// Spatial order by k-d median splits along the longest axis of the centres; every left part is a
-// whole number of runs, so consecutive runs of `run` in the result are the leaves.  Ties are broken
-// by index: the order is a function of the scene alone.
-void group_order(const std::vector<DevSph> &sph, int run, std::vector<int32_t> &order) {
+// Spatial order by k-d median splits along the longest axis of the centres.  Every left part is a
+// whole number of `big` runs while more than one is left, and of `run`s below that, so consecutive
+// runs of `big` (super-groups) and of `run` (groups) in the result are subtrees.  Ties are broken by
+// index: the order is a function of the scene alone.
+void group_order(const std::vector<DevSph> &sph, int run, int big, std::vector<int32_t> &order) {
   order.resize(sph.size());
   std::iota(order.begin(), order.end(), 0);
   struct Split {
-    static void go(const std::vector<DevSph> &sph, int run, int32_t *idx, size_t n) {
-      if (n <= (size_t)run) {
+    static void go(const std::vector<DevSph> &sph, int small, int big, int32_t *idx, size_t n) {
+      const int run = n > (size_t)big ? big : small;
+      if (n <= (size_t)small) {
         std::sort(idx, idx + n);
         return;
       }
@@ -520,11 +522,11 @@ void group_order(const std::vector<DevSph> &sph, int run, std::vector<int32_t> &
         const float cb = ax == 0 ? sph[(size_t)b].cx : ax == 1 ? sph[(size_t)b].cy : sph[(size_t)b].cz;
         return ca < cb || (ca == cb && a < b);
       });
-      go(sph, run, idx, left);
-      go(sph, run, idx + left, n - left);
+      go(sph, small, big, idx, left);
+      go(sph, small, big, idx + left, n - left);
     }
   };
-  Split::go(sph, run, order.data(), order.size());
+  Split::go(sph, run, big, order.data(), order.size());
 }
 
 // Bounding sphere of the spheres order[first .. first + count): centre = middle of the box around

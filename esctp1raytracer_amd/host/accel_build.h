@@ -61,9 +61,10 @@ void sphere_boxes(const std::vector<DevSph> &sph, const OriginBounds &ob,
 void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, int max_depth,
                BuiltBvh &out);
 
-// Sphere groups of the brute-force primary pass (rt_device.h SphGroups): a spatial order whose
-// consecutive runs of `run` spheres are neighbours, and the bounding sphere of one run.
-void group_order(const std::vector<DevSph> &sph, int run, std::vector<int32_t> &order);
+// Sphere groups of the brute-force passes (rt_device.h SphGroups): a spatial order whose
+// consecutive runs of `run` spheres (groups) and of `big` spheres (super-groups; a multiple of
+// `run`) are neighbours, and the bounding sphere of one run.
+void group_order(const std::vector<DevSph> &sph, int run, int big, std::vector<int32_t> &order);
 DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, int count);
 
 } // namespace esc
