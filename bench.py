@@ -93,6 +93,10 @@ def parse():
                          "makes the opt-in acceleration structure the measured path")
     ap.add_argument("--no-accel", action="store_true",
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="render default-path frames only (no index-order frame for the reference's "
+                         "test count): what tools/profile.sh wants under rocprofv3, so that every "
+                         "launch in the trace belongs to a timed frame's path")
     ap.add_argument("--pipelined", action="store_true",
                     help="N=1: also time the same K frames with two in flight on two streams "
                          "(information only; off by default so that a rocprofv3 trace of the "
@@ -385,7 +389,7 @@ def main():
     # the reference's any-hit count: one frame in index order (the default sweeps long sphere lists
     # in another order for the last light and so executes fewer tests; the image is the same)
     anyhit_index_order = None
-    if world == 1 and a.stage != "bvh":
+    if world == 1 and a.stage != "bvh" and not a.profile_run:
         r.synchronize()
         r.reset_counters()
         with torch.cuda.stream(st):

@@ -740,6 +740,145 @@ DEVINL void closest_tri_primary_filter(FetchP recp, FetchF recf, FetchE rece, in
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Triangle GROUPS (rt_device.h TriGroups): the pre-filter's two statements, lifted from one
+// triangle to 8 (a group) and 64 (a super-group) that are neighbours in space.  For a member t the
+// pre-filter's proof gives: a reference accept has (S_t) the line through o'_t = v0 + tvec within
+// 2 rho_t of the centroid G_t, or (E_t) |det*| < tau_t.
+//  (S_t): o'_t is within 1.01u |tvec_t|_1 of the camera o, C~ = o - fl(o - C) within 1.01u A of the
+//   stored centre C (A = |fl(o - C)|_1), |tvec_t|_1 <= (A + rext)(1 + 2u); with rgeo >= |G_t - C| +
+//   2 rho_t the line through o passes C~ within  R := rgeo + 8u (A + rext) + 2^-60, and (C, R) goes
+//   through the scaled sphere record exactly as a sphere group's (C, R) does: |b''| >= 1.
+//  (E_t): |d . n_t| < tau_t / |n1_t| <= b0 + b1 |tvec_t|_1 for the unit normal n_t (tau_t's formula is
+//   linear in |tvec|: host, tri_group_bounds).  With a unit axis a and sin(angle(a, +-n_t)) <= smax:
+//   |d . a| <= |d . n_t| + |d| smax.  The record holds a / kappa', kappa' = (smax + b0 + b1 (A + rext)
+//   + 2^-20) * 1.0001, so |g''| <= 1 for the FMA chain (its own 3.01u |a|_1 / kappa' sits inside
+//   the 2^-20).  kappa' >= 1 (no useful cone), a sliver among the members: the group is always open.
+// A member accept therefore opens its group and super-group; inside an opened group the per-triangle
+// pre-filter, the filter and the reference arithmetic run as before.  Order: as for the sphere
+// groups, an equal closest t goes to the lower ORIGINAL index.
+// ---------------------------------------------------------------------------------------
+DEVINL void test_tri2_primary_sorted(const DevTriP (&T)[2], int id0, int id1, const V3<v2f> &d,
+                                     Hit (&h)[2]) {
+  v2f det[2], un[2], vn[2];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const V3<v2f> pv = cross_vu(d, ld3(T[i].e2)); // ray_triangle.h:18
+    det[i] = dotu(ld3(T[i].e1), pv);              // :21
+    un[i] = dotu(ld3(T[i].tv), pv);               // :32 numerator
+    vn[i] = dotu(ld3(T[i].qv), d);                // :40 numerator
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      any |= tri_candidate(comp(det[i], c), comp(un[i], c), comp(vn[i], c));
+  }
+  if (ANY_LANE_RARE(any)) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float de = comp(det[i], c), u = comp(un[i], c), v = comp(vn[i], c);
+        float t2, v2;
+        if (tri_candidate(de, u, v) && tri_exact_nb(de, u, v, T[i].tnum, t2, v2)) {
+          const int id = i ? id1 : id0;
+          if (t2 < h[c].t || (t2 == h[c].t && id < h[c].idx)) {
+            h[c].t = t2;
+            h[c].v = v2;
+            h[c].idx = id;
+          }
+        }
+      }
+  }
+}
+
+// n_sup is a multiple of kTriGroupStep (= 4; pad records never open).  Super-group s holds groups
+// [8 s, 8 s + 8), group g the sorted slots [8 g, 8 g + 8).
+template <typename FetchP, typename FetchF, typename FetchE, typename FetchI>
+DEVINL void closest_tri_primary_groups(FetchP recu, FetchP recg, FetchP recp, FetchF recf, FetchE rece,
+                                       FetchI reci, int n_sup, const V3<v2f> &d, Hit (&h)[2]) {
+  static_assert(kTriGroup == 8 && kTriSuper == 8 && kTriGroupStep == 4, "4-wide bodies below");
+  auto level2 = [&](int k) { // sorted triangles k, k+1 (k even)
+    const TriF T[2] = {recf(k), recf(k + 1)};
+    v2f A[2], B[2], C[2];
+    tri2_primary_filter_pk(T, d.x, d.y, d.z, A, B, C);
+    const int m = tri_flags(A[1], B[1], C[1], tri_flags(A[0], B[0], C[0], -1));
+    if (ANY_LANE_RARE(m >= 0)) {
+      const DevTriP E[2] = {rece(k), rece(k + 1)};
+      const DevIdx4 I = reci(k >> 2);
+      test_tri2_primary_sorted(E, (k & 2) ? I.v[2] : I.v[0], (k & 2) ? I.v[3] : I.v[1], d, h);
+    }
+  };
+  // pre-filter body on 4 records x 2 pixels: per-lane flags of the two record pairs
+  auto flags4 = [&](const TriPF(&T)[4], v2f (&b)[4], v2f (&g)[4], bool &f0, bool &f1) {
+    tri4_primary_prefilter_pk(T, d.x, d.y, d.z, b, g);
+    float mx0 = 0.f, mn0 = 2.f, mx1 = 0.f, mn1 = 2.f;
+    maxmin_abs4(b[0], b[1], g[0], g[1], mx0, mn0);
+    maxmin_abs4(b[2], b[3], g[2], g[3], mx1, mn1);
+    f0 = (mx0 >= 1.f) | (mn0 <= 1.f);
+    f1 = (mx1 >= 1.f) | (mn1 <= 1.f);
+  };
+  auto members4 = [&](int k) { // sorted triangles k .. k+3: pre-filter, filter, reference arithmetic
+    TriPF T[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[i] = recp(k + i);
+    v2f b[4], g[4];
+    bool f0, f1;
+    flags4(T, b, g, f0, f1);
+    if (ANY_LANE_RARE(f0 | f1)) {
+      if (__builtin_amdgcn_ballot_w64(f0)) level2(k);
+      if (__builtin_amdgcn_ballot_w64(f1)) level2(k + 2);
+    }
+  };
+  // wave-uniform mask of the records (groups / super-groups) some lane must open
+  auto open4 = [&](const TriPF(&T)[4]) -> uint32_t {
+    v2f b[4], g[4];
+    bool f0, f1;
+    flags4(T, b, g, f0, f1);
+    uint32_t mask = 0;
+    if (ANY_LANE_RARE(f0 | f1)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool c = (fmaxf(fabsf(b[j].x), fabsf(b[j].y)) >= 1.f) ||
+                       (fminf(fabsf(g[j].x), fabsf(g[j].y)) <= 1.f);
+        if (__builtin_amdgcn_ballot_w64(c)) mask |= 1u << j;
+      }
+    }
+    return mask;
+  };
+  auto groups = [&](int s) { // the 8 groups of super-group s, 4 at a time
+    for (int half = 0; half < 2; ++half) {
+      TriPF G[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) G[i] = recg(8 * s + 4 * half + i);
+      uint32_t mask = open4(G);
+      while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        const int g0 = 8 * (8 * s + 4 * half + j);
+        members4(g0);
+        members4(g0 + 4);
+      }
+    }
+  };
+  auto step = [&](const TriPF(&U)[4], int s0) {
+    uint32_t mask = open4(U);
+    while (mask) {
+      const int j = __builtin_ctz(mask);
+      mask &= mask - 1;
+      groups(s0 + j);
+    }
+  };
+  TriPF A[4], B[4];
+  fetch_batch(recu, 0, A);
+  for (int s = 0; s < n_sup; s += 8) {
+    fetch_batch(recu, recu.landed(A[3].gz, min(s + 4, n_sup - 4)), B);
+    step(A, s);
+    if (s + 4 >= n_sup) break;
+    fetch_batch(recu, recu.landed(B[3].gz, min(s + 8, n_sup - 4)), A);
+    step(B, s + 4);
+  }
+}
+
 struct TriPairF { // DevTriPairF as sixteen aligned pairs
   v2f n1x, n1y, n1z, e1x, e1y, e1z, e2x, e2y, e2z, k1x, k1y, k1z, k2x, k2y, k2z, M;
 };

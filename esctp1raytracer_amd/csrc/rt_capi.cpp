@@ -22,7 +22,8 @@ static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNod
 
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevTriF *tri_f, esc::DevTriPF *tri_pf, esc::DevSphP *sph_p,
-                                  esc::DevSphF *sph_f, const esc::SphGroups *sg, hipStream_t stream);
+                                  esc::DevSphF *sph_f, const esc::SphGroups *sg,
+                                  const esc::TriGroups *tg, hipStream_t stream);
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
@@ -67,7 +68,8 @@ struct esc_context {
   esc::DevSphPairF *d_sph2_f = nullptr;
   esc::DevSphPair *d_sph2_ord = nullptr;    // last light's sweep order (rt_device.h sph2_ord)
   esc::DevSphPairF *d_sph2_f_ord = nullptr;
-  esc::SphGroups sg{};                  // sphere groups of the primary pass (all pointers owned)
+  esc::SphGroups sg{};                  // sphere groups (all pointers owned)
+  esc::TriGroups tg{};                  // triangle groups (all pointers owned)
   esc::DevTriF *d_tri_f = nullptr;
   esc::DevTriPairF *d_tri2_f = nullptr;
   esc::DevTriPF *d_tri_pf = nullptr;       // pre-filter forms (rt_brute.h "Triangle pre-filter")
@@ -356,7 +358,8 @@ int commit(esc_context *ctx, const Staged &s) {
   }
   // filter form of the triangle table for shadow rays (rt_brute.h "Triangle FILTERS"), in double,
   // margins rounded up
-  std::vector<esc::DevTriPairF> tri2f((s.tri.size() + 1) / 2);
+  auto build_tri2f = [&](const std::vector<esc::DevTri> &src) {
+  std::vector<esc::DevTriPairF> tri2f((src.size() + 1) / 2);
   for (size_t j = 0; j < tri2f.size(); j++)
     for (int h = 0; h < 2; h++) {
       esc::DevTriPairF &F = tri2f[j];
@@ -364,12 +367,12 @@ int commit(esc_context *ctx, const Staged &s) {
       float *f[15] = {&F.n1x[h], &F.n1y[h], &F.n1z[h], &F.e1x[h], &F.e1y[h], &F.e1z[h], &F.e2x[h],
                       &F.e2y[h], &F.e2z[h], &F.k1x[h], &F.k1y[h], &F.k1z[h], &F.k2x[h], &F.k2y[h],
                       &F.k2z[h]};
-      if (k >= s.tri.size()) {
+      if (k >= src.size()) {
         for (float *x : f) *x = 0.f;
         F.M[h] = -1.f; // A = 0*0 + M < 0: never a candidate
         continue;
       }
-      const esc::DevTri &t = s.tri[k];
+      const esc::DevTri &t = src[k];
       const float v[3] = {(float)((double)t.v0[0] - g[0]), (float)((double)t.v0[1] - g[1]),
                           (float)((double)t.v0[2] - g[2])};
       const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]},
@@ -399,6 +402,9 @@ int commit(esc_context *ctx, const Staged &s) {
       if ((double)Mf < M) Mf = std::nextafterf(Mf, __builtin_huge_valf());
       F.M[h] = Mf;
     }
+  return tri2f;
+  };
+  const std::vector<esc::DevTriPairF> tri2f = build_tri2f(s.tri);
   std::vector<esc::DevSphPairF> sph2f(sph2.size());
   for (size_t j = 0; j < sph2f.size(); j++)
     for (int h = 0; h < 2; h++) {
@@ -423,7 +429,8 @@ int commit(esc_context *ctx, const Staged &s) {
     }
   // pre-filter form of the triangle table for shadow rays (rt_brute.h "Triangle pre-filter"):
   // bounding sphere (G, R) in DevSphPairF form + the normal scaled by 1 / tau', in double
-  std::vector<esc::DevTriPairPF> tri2pf(tri2f.size());
+  auto build_tri2pf = [&](const std::vector<esc::DevTri> &src) {
+  std::vector<esc::DevTriPairPF> tri2pf((src.size() + 1) / 2);
   for (size_t j = 0; j < tri2pf.size(); j++)
     for (int h = 0; h < 2; h++) {
       esc::DevTriPairPF &F = tri2pf[j];
@@ -431,14 +438,14 @@ int commit(esc_context *ctx, const Staged &s) {
       F.cx[h] = F.cy[h] = F.cz[h] = 0.f;
       F.gx[h] = F.gy[h] = F.gz[h] = F.pad[h] = 0.f;
       F.km[h] = -__builtin_huge_valf(); // pad half: never a candidate, never "nearly parallel" ...
-      if (k >= s.tri.size()) {
+      if (k >= src.size()) {
         F.gx[h] = 4.f; // ... (|L . (4,4,4)| >= 4 / sqrt(3) > 1 for a unit L)
         F.gy[h] = 4.f;
         F.gz[h] = 4.f;
         continue;
       }
       F.km[h] = __builtin_huge_valf(); // sliver: always a candidate (g'' = 0 too)
-      const esc::DevTri &t = s.tri[k];
+      const esc::DevTri &t = src[k];
       const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
       double G[3], s3[3], r0 = 0, r1 = 0, r2 = 0, l1 = 0, l2 = 0, a1 = 0, a2 = 0, av = 0;
       for (int a = 0; a < 3; a++) {
@@ -476,6 +483,9 @@ int commit(esc_context *ctx, const Staged &s) {
       F.gy[h] = (float)(n1[1] / taup);
       F.gz[h] = (float)(n1[2] / taup);
     }
+  return tri2pf;
+  };
+  const std::vector<esc::DevTriPairPF> tri2pf = build_tri2pf(s.tri);
   // the LAST light's sweep order (ESC_RENDER_INDEX_ORDER switches it off): spheres by decreasing
   // solid angle r^2 / |c - P|^2 seen from its first sample point P.  Same records, permuted pair
   // tables (exact + filter); from 256 spheres up.
@@ -601,8 +611,114 @@ int commit(esc_context *ctx, const Staged &s) {
       filter_half(sg_grp2f[j], h, G.cx, G.cy, G.cz, R * R * 1.00001);
     }
   }
+  // triangle groups (rt_device.h TriGroups): spatial order, groups of 8, super-groups of 8 groups,
+  // padded to whole sweep steps; the shadow forms of the sorted triangles and of the groups
+  std::vector<esc::DevTri> tg_sorted;
+  std::vector<esc::DevTriGroup> tg_grp;
+  std::vector<esc::DevIdx4> tg_orig;
+  std::vector<esc::DevTriPairF> tg_sorted2f;
+  std::vector<esc::DevTriPairPF> tg_sorted2pf, tg_grp2pf;
+  size_t tg_n_grp = 0;
+  if ((int)s.tri.size() >= esc::kTriGroupMinTris) {
+    constexpr size_t kBig = (size_t)esc::kTriGroup * esc::kTriSuper;
+    std::vector<int32_t> order;
+    esc::group_order(s.tri, esc::kTriGroup, (int)kBig, order);
+    const size_t n_real = (s.tri.size() + esc::kTriGroup - 1) / esc::kTriGroup;
+    const size_t n_sup_real = (s.tri.size() + kBig - 1) / kBig;
+    const size_t n_sup = (n_sup_real + esc::kTriGroupStep - 1) / esc::kTriGroupStep * esc::kTriGroupStep;
+    const size_t n_grp = n_sup * esc::kTriSuper;
+    esc::DevTri pad_t;
+    std::memset(&pad_t, 0, sizeof(pad_t));
+    tg_sorted.assign(n_grp * esc::kTriGroup, pad_t);
+    esc::DevTriGroup pad_g;
+    std::memset(&pad_g, 0, sizeof(pad_g));
+    pad_g.rgeo = -1.f;
+    tg_grp.assign(n_grp + n_sup, pad_g);
+    esc::DevIdx4 pad_i;
+    pad_i.v[0] = pad_i.v[1] = pad_i.v[2] = pad_i.v[3] = INT32_MAX / 2;
+    tg_orig.assign(n_grp * esc::kTriGroup / 4, pad_i);
+    for (size_t k = 0; k < order.size(); k++) {
+      tg_sorted[k] = s.tri[(size_t)order[k]];
+      tg_orig[k >> 2].v[k & 3] = order[k];
+    }
+    for (size_t j = 0; j < n_real; j++) {
+      const size_t first = j * esc::kTriGroup;
+      tg_grp[j] = esc::tri_group_bounds(s.tri, order.data() + first,
+                                        (int)std::min((size_t)esc::kTriGroup, order.size() - first));
+    }
+    for (size_t j = 0; j < n_sup_real; j++) {
+      const size_t first = j * kBig;
+      tg_grp[n_grp + j] =
+          esc::tri_group_bounds(s.tri, order.data() + first, (int)std::min(kBig, order.size() - first));
+    }
+    tg_n_grp = n_grp;
+    tg_sorted2f = build_tri2f(tg_sorted);
+    tg_sorted2pf = build_tri2pf(tg_sorted);
+    tg_grp2pf.resize(tg_grp.size() / 2);
+    for (size_t k = 0; k < tg_grp.size(); k++) {
+      const esc::DevTriGroup &G = tg_grp[k];
+      esc::DevTriPairPF &F = tg_grp2pf[k >> 1];
+      const int h = (int)(k & 1);
+      F.cx[h] = F.cy[h] = F.cz[h] = 0.f;
+      F.gx[h] = F.gy[h] = F.gz[h] = F.pad[h] = 0.f;
+      if (G.rgeo < 0.f) { // pad group: never a candidate, never "nearly parallel"
+        F.km[h] = -__builtin_huge_valf();
+        F.gx[h] = F.gy[h] = F.gz[h] = 0x1p60f;
+        continue;
+      }
+      F.km[h] = __builtin_huge_valf(); // always open unless the bounds below are usable
+      if (G.always != 0.f) continue;
+      const float c[3] = {(float)((double)G.cx - g[0]), (float)((double)G.cy - g[1]),
+                          (float)((double)G.cz - g[2])};
+      const double c1 = std::fabs((double)G.cx - g[0]) + std::fabs((double)G.cy - g[1]) +
+                        std::fabs((double)G.cz - g[2]);
+      const double at = rho + c1 + (double)G.rext; // >= |O - v0_t|_1 for every member and ray in range
+      const double kappa = ((double)G.smax + (double)G.b0 + (double)G.b1 * at + 0x1p-20) * 1.0001;
+      if (!(kappa < 1.0)) continue;
+      const double R = (double)G.rgeo + 0x1p-21 * at + 0x1p-60;
+      const double c2 = (double)c[0] * c[0] + (double)c[1] * c[1] + (double)c[2] * c[2];
+      const double R2 = R * R * 1.00001;
+      const double km = R2 - c2 + 0x1p-16 * (c2 + R2) + 0x1p-120;
+      if (!std::isfinite(km)) continue;
+      float kf = (float)km;
+      if ((double)kf < km) kf = std::nextafterf(kf, __builtin_huge_valf());
+      F.cx[h] = c[0];
+      F.cy[h] = c[1];
+      F.cz[h] = c[2];
+      F.km[h] = kf;
+      F.gx[h] = (float)((double)G.ax / kappa);
+      F.gy[h] = (float)((double)G.ay / kappa);
+      F.gz[h] = (float)((double)G.az / kappa);
+    }
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read old tables
   int rc;
+  {
+    esc::DevTri *d_t = const_cast<esc::DevTri *>(ctx->tg.sorted);
+    esc::DevIdx4 *d_o = const_cast<esc::DevIdx4 *>(ctx->tg.orig);
+    esc::DevTriGroup *d_g = const_cast<esc::DevTriGroup *>(ctx->tg.grp);
+    esc::DevTriPairPF *d_s2pf = const_cast<esc::DevTriPairPF *>(ctx->tg.sorted2_pf);
+    esc::DevTriPairF *d_s2f = const_cast<esc::DevTriPairF *>(ctx->tg.sorted2_f);
+    esc::DevTriPairPF *d_g2pf = const_cast<esc::DevTriPairPF *>(ctx->tg.grp2_pf);
+    if ((rc = upload_vec(d_t, tg_sorted, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_o, tg_orig, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_g, tg_grp, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_s2pf, tg_sorted2pf, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_s2f, tg_sorted2f, ctx->stream))) return rc;
+    if ((rc = upload_vec(d_g2pf, tg_grp2pf, ctx->stream))) return rc;
+    ctx->tg.sorted = d_t;
+    ctx->tg.orig = d_o;
+    ctx->tg.grp = d_g;
+    ctx->tg.sorted2_pf = d_s2pf;
+    ctx->tg.sorted2_f = d_s2f;
+    ctx->tg.grp2_pf = d_g2pf;
+    if ((rc = alloc_dev(ctx->tg.sorted_p, tg_sorted.size()))) return rc;
+    if ((rc = alloc_dev(ctx->tg.sorted_f, tg_sorted.size()))) return rc;
+    if ((rc = alloc_dev(ctx->tg.sorted_pf, tg_sorted.size()))) return rc;
+    if ((rc = alloc_dev(ctx->tg.grp_pf, tg_grp.size()))) return rc;
+    ctx->tg.n_grp = (int32_t)tg_n_grp;
+    ctx->tg.n_sup = (int32_t)(tg_grp.size() - tg_n_grp);
+  }
   {
     esc::DevSphPair *d_s2 = const_cast<esc::DevSphPair *>(ctx->sg.sorted2);
     esc::DevSphPairF *d_s2f = const_cast<esc::DevSphPairF *>(ctx->sg.sorted2_f);
@@ -838,6 +954,12 @@ void esc_context_destroy(esc_context *ctx) {
                   const_cast<esc::DevSphPair *>(ctx->sg.sorted2),
                   const_cast<esc::DevSphPairF *>(ctx->sg.sorted2_f),
                   const_cast<esc::DevSphPairF *>(ctx->sg.grp2_f),
+                  const_cast<esc::DevTri *>(ctx->tg.sorted), const_cast<esc::DevIdx4 *>(ctx->tg.orig),
+                  const_cast<esc::DevTriGroup *>(ctx->tg.grp),
+                  const_cast<esc::DevTriPairPF *>(ctx->tg.sorted2_pf),
+                  const_cast<esc::DevTriPairF *>(ctx->tg.sorted2_f),
+                  const_cast<esc::DevTriPairPF *>(ctx->tg.grp2_pf), ctx->tg.sorted_p, ctx->tg.sorted_f,
+                  ctx->tg.sorted_pf, ctx->tg.grp_pf,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits, ctx->d_sq, ctx->d_sq_ctl,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,
@@ -1176,7 +1298,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       return e && std::strcmp(e, "0") == 0;
     }();
     p.sg = ctx->sg;
-    if (index_order || env_nogroups) p.sg.n_grp = p.sg.n_sup = 0;
+    p.tg = ctx->tg;
+    if (index_order || env_nogroups) p.sg.n_grp = p.sg.n_sup = p.tg.n_grp = p.tg.n_sup = 0;
 
   }
   p.tri_f = ctx->d_tri_f;
@@ -1221,7 +1344,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
 
   if (!ctx->prepared || std::memcmp(ctx->prepared_origin, cam->origin, 12) != 0) {
     int e = esc_launch_prepare(&p, ctx->d_tri_p, ctx->d_tri_f, ctx->d_tri_pf, ctx->d_sph_p,
-                               ctx->d_sph_f, &ctx->sg, ctx->stream);
+                               ctx->d_sph_f, &ctx->sg, &ctx->tg, ctx->stream);
     if (e) {
       set_error(std::string("k_prepare_primary launch: ") + hipGetErrorString((hipError_t)e));
       return ESC_ERR_HIP;

@@ -184,6 +184,42 @@ struct DevLight {
   int32_t n_faces;
 };
 
+// ---------------------------------------------------------------------------------------
+// Triangle GROUPS (rt_brute.h "Triangle GROUPS"): the sphere groups' two levels for triangles.  The
+// triangles are put in a spatial order (k-d splits over the centroids), cut into groups of 8 and
+// super-groups of 8 groups.  A group record has the form of a triangle's pre-filter record
+// (DevTriPF / DevTriPairPF): the bounding sphere of the members' pre-filter spheres, and -- for the
+// pre-filter's "nearly parallel" escape -- the axis a of a cone that holds every member's normal
+// line, scaled by 1 / kappa with kappa >= sin(cone half-angle) + max tau' / |n1|: a ray nearly
+// parallel to ANY member has |d . a| <= kappa.  Static part per group:
+// ---------------------------------------------------------------------------------------
+constexpr int kTriGroup = 8;
+constexpr int kTriSuper = 8;
+constexpr int kTriGroupStep = 4; // super-groups per sweep step: n_sup is a multiple of this
+constexpr int kTriGroupMinTris = 64;
+struct alignas(16) DevTriGroup {
+  float cx, cy, cz, rgeo; // rgeo >= |G_t - C| + 2 rho_t for every member (G_t centroid, rho_t its
+                          // bounding radius); rgeo < 0: pad group
+  float ax, ay, az, smax; // unit axis; smax >= |a x n_t / |n_t|| for every member
+  float rext;             // >= |v0_t - C|_1 + |e1_t|_1 + |e2_t|_1 for every member
+  float b0, b1;           // tau_t / |n1_t| <= b0 + b1 |tvec_t|_1 for every member (rt_brute.h)
+  float always;           // != 0: always open (a sliver among the members, or no useful cone)
+};
+struct TriGroups {
+  int32_t n_grp, n_sup;          // n_grp = 8 n_sup; 0: no groups
+  const DevTri *sorted;          // n_grp * kTriGroup triangles in group order; pads are all zeros
+  const DevIdx4 *orig;           // original index of each sorted slot, 4 per record
+  const DevTriGroup *grp;        // n_grp groups, then n_sup super-groups
+  DevTriP *sorted_p;             // per frame: the forms of `sorted` ...
+  DevTriF *sorted_f;
+  DevTriPF *sorted_pf;
+  DevTriPF *grp_pf;              // ... and of the groups / super-groups
+  // shadow rays of the last light: static, two per record
+  const DevTriPairPF *sorted2_pf;
+  const DevTriPairF *sorted2_f;
+  const DevTriPairPF *grp2_pf;   // n_grp / 2 records, then n_sup / 2
+};
+
 // hand-over between k_primary and k_shade: the closest hit of every pixel of the band
 // (main.cpp:715-722 state) as three planes of n_pixels dwords each, so every store / load is a
 // run of consecutive dwords:
@@ -359,7 +395,8 @@ struct RenderParams {
   uint8_t *out_u8;  // band-local, may be null
   // kCounterSets replicas of {primary, hit, shadow rays, any-hit tests, 4 spare}, 64 B each
   unsigned long long *counters;
-  SphGroups sg;                 // primary rays: sphere groups
+  SphGroups sg;                 // sphere groups (both passes)
+  TriGroups tg;                 // triangle groups (both passes)
   ShadeQueue sq;                // queue form of the shadow pass (brute force, large scenes)
   HitPlanes hits;               // band-local, n_local_rows * W pixels (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only

@@ -68,6 +68,75 @@ DEVINL DevSphF sphere_filter_record(f3 oc, float cc, float r2a) {
   return F;
 }
 
+// per-frame forms of one triangle for rays leaving o: the exact hoisted record (DevTriP), the
+// filter (DevTriF) and the pre-filter (DevTriPF) -- rt_brute.h
+DEVINL void tri_primary_records(const DevTri &T, f3 o, DevTriP &Pout, DevTriF &Fout, DevTriPF &Qout) {
+  const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+  const f3 tv = o - ld3(T.v0);   // ray_triangle.h:29
+  const f3 qv = cross(tv, e1);   // :37
+  DevTriP P;
+  P.e2[0] = e2.x; P.e2[1] = e2.y; P.e2[2] = e2.z;
+  P.e1[0] = e1.x; P.e1[1] = e1.y; P.e1[2] = e1.z;
+  P.tv[0] = tv.x; P.tv[1] = tv.y; P.tv[2] = tv.z;
+  P.qv[0] = qv.x; P.qv[1] = qv.y; P.qv[2] = qv.z;
+  P.tnum = dot(e2, qv);          // :45 numerator
+  P.pad[0] = P.pad[1] = P.pad[2] = 0.f;
+  Pout = P;
+  { // filter form (rt_brute.h "Triangle FILTERS"): n1 = e2 x e1, n2 = e2 x tv, n3 = qv
+    const f3 n1 = cross(e2, e1), n2 = cross(e2, tv);
+    const float a1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z);
+    const float a2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
+    const float at = (fabsf(tv.x) + fabsf(tv.y)) + fabsf(tv.z);
+    const float aq = (fabsf(qv.x) + fabsf(qv.y)) + fabsf(qv.z);
+    const float p12 = a1 * a2;
+    DevTriF F;
+    F.n1[0] = n1.x; F.n1[1] = n1.y; F.n1[2] = n1.z;
+    F.n2[0] = n2.x; F.n2[1] = n2.y; F.n2[2] = n2.z;
+    F.n3[0] = qv.x; F.n3[1] = qv.y; F.n3[2] = qv.z;
+    F.M = p12 * ((p12 + at * a2) + aq) * 0x1p-17f + 0x1p-120f;
+    F.pad[0] = F.pad[1] = 0.f;
+    Fout = F;
+    // pre-filter form (rt_brute.h "Triangle pre-filter"): bounding sphere (G, R = 2 rho + slack)
+    // seen from the ray origin o' = v0 + tv, and the normal scaled by 1 / tau'
+    const f3 s3 = (e1 + e2) * (1.f / 3.f);
+    const f3 ocg = tv - s3; // o' - G
+    const float rho = sqrtf(fmaxf(fmaxf(dot(s3, s3), dot(e1 - s3, e1 - s3)), dot(e2 - s3, e2 - s3))) *
+                      1.00001f;
+    const float emax = sqrtf(fmaxf(dot(e1, e1), dot(e2, e2))) * 1.00001f;
+    DevTriPF Q;
+    Q.sx = Q.sy = Q.sz = 0.f;
+    Q.w = 2.f; // always a candidate ...
+    Q.gx = Q.gy = Q.gz = Q.pad = 0.f; // ... and always "grazing" (|0| <= 1)
+    if (rho > 0x1p-10f * emax) { // ... unless the triangle is not a sliver
+      // tau: |det| >= tau keeps the accepted hit within rho of the triangle; tau' adds what the
+      // filter's own det can be off by
+      const float tau = 0x1.99999ap+1f * 0x1p-24f * ((10.04f * at * a2 + 5.04f * at * a1) + 20.1f * p12) *
+                        emax / rho;
+      const float taup = (tau + 0x1.44p+3f * 0x1p-24f * p12) * 1.00001f + 0x1p-120f; // + 10.1u P12
+      const float R = 2.f * rho + 0x1p-21f * ((at + a1) + a2); // + 8u (|tv| + |e1| + |e2|)
+      const float A = (fabsf(ocg.x) + fabsf(ocg.y)) + fabsf(ocg.z);
+      const float R2 = R * R * 1.00001f;
+      const float ccg = dot(ocg, ocg) - R2;
+      const float ccm = ccg - ((A * A + R2) * 0x1p-19f + 0x1p-120f);
+      if (ccm > 0.f) {
+        const float sc = (sqrtf(ccm) * 0x1.fffff8p-1f - A * 0x1.2p-21f) * 0x1.fffff8p-1f;
+        if (sc > 0.f) {
+          const float inv = 1.f / sc;
+          Q.sx = ocg.x * inv;
+          Q.sy = ocg.y * inv;
+          Q.sz = ocg.z * inv;
+          Q.w = 0.f;
+        }
+      }
+      const float ig = 1.f / taup;
+      Q.gx = n1.x * ig;
+      Q.gy = n1.y * ig;
+      Q.gz = n1.z * ig;
+    }
+    Qout = Q;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
                   DevTriF *__restrict__ tri_f, DevTriPF *__restrict__ tri_pf, int n_tri,
@@ -76,71 +145,7 @@ k_prepare_primary(const DevTri *__restrict__ tri, DevTriP *__restrict__ tri_p,
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const f3 o = mk(ox, oy, oz);
   if (i < n_tri) {
-    const DevTri T = tri[i];
-    const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
-    const f3 tv = o - ld3(T.v0);   // ray_triangle.h:29
-    const f3 qv = cross(tv, e1);   // :37
-    DevTriP P;
-    P.e2[0] = e2.x; P.e2[1] = e2.y; P.e2[2] = e2.z;
-    P.e1[0] = e1.x; P.e1[1] = e1.y; P.e1[2] = e1.z;
-    P.tv[0] = tv.x; P.tv[1] = tv.y; P.tv[2] = tv.z;
-    P.qv[0] = qv.x; P.qv[1] = qv.y; P.qv[2] = qv.z;
-    P.tnum = dot(e2, qv);          // :45 numerator
-    P.pad[0] = P.pad[1] = P.pad[2] = 0.f;
-    tri_p[i] = P;
-    { // filter form (rt_brute.h "Triangle FILTERS"): n1 = e2 x e1, n2 = e2 x tv, n3 = qv
-      const f3 n1 = cross(e2, e1), n2 = cross(e2, tv);
-      const float a1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z);
-      const float a2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
-      const float at = (fabsf(tv.x) + fabsf(tv.y)) + fabsf(tv.z);
-      const float aq = (fabsf(qv.x) + fabsf(qv.y)) + fabsf(qv.z);
-      const float p12 = a1 * a2;
-      DevTriF F;
-      F.n1[0] = n1.x; F.n1[1] = n1.y; F.n1[2] = n1.z;
-      F.n2[0] = n2.x; F.n2[1] = n2.y; F.n2[2] = n2.z;
-      F.n3[0] = qv.x; F.n3[1] = qv.y; F.n3[2] = qv.z;
-      F.M = p12 * ((p12 + at * a2) + aq) * 0x1p-17f + 0x1p-120f;
-      F.pad[0] = F.pad[1] = 0.f;
-      tri_f[i] = F;
-      // pre-filter form (rt_brute.h "Triangle pre-filter"): bounding sphere (G, R = 2 rho + slack)
-      // seen from the ray origin o' = v0 + tv, and the normal scaled by 1 / tau'
-      const f3 s3 = (e1 + e2) * (1.f / 3.f);
-      const f3 ocg = tv - s3; // o' - G
-      const float rho = sqrtf(fmaxf(fmaxf(dot(s3, s3), dot(e1 - s3, e1 - s3)), dot(e2 - s3, e2 - s3))) *
-                        1.00001f;
-      const float emax = sqrtf(fmaxf(dot(e1, e1), dot(e2, e2))) * 1.00001f;
-      DevTriPF Q;
-      Q.sx = Q.sy = Q.sz = 0.f;
-      Q.w = 2.f; // always a candidate ...
-      Q.gx = Q.gy = Q.gz = Q.pad = 0.f; // ... and always "grazing" (|0| <= 1)
-      if (rho > 0x1p-10f * emax) { // ... unless the triangle is not a sliver
-        // tau: |det| >= tau keeps the accepted hit within rho of the triangle; tau' adds what the
-        // filter's own det can be off by
-        const float tau = 0x1.99999ap+1f * 0x1p-24f * ((10.04f * at * a2 + 5.04f * at * a1) + 20.1f * p12) *
-                          emax / rho;
-        const float taup = (tau + 0x1.44p+3f * 0x1p-24f * p12) * 1.00001f + 0x1p-120f; // + 10.1u P12
-        const float R = 2.f * rho + 0x1p-21f * ((at + a1) + a2); // + 8u (|tv| + |e1| + |e2|)
-        const float A = (fabsf(ocg.x) + fabsf(ocg.y)) + fabsf(ocg.z);
-        const float R2 = R * R * 1.00001f;
-        const float ccg = dot(ocg, ocg) - R2;
-        const float ccm = ccg - ((A * A + R2) * 0x1p-19f + 0x1p-120f);
-        if (ccm > 0.f) {
-          const float sc = (sqrtf(ccm) * 0x1.fffff8p-1f - A * 0x1.2p-21f) * 0x1.fffff8p-1f;
-          if (sc > 0.f) {
-            const float inv = 1.f / sc;
-            Q.sx = ocg.x * inv;
-            Q.sy = ocg.y * inv;
-            Q.sz = ocg.z * inv;
-            Q.w = 0.f;
-          }
-        }
-        const float ig = 1.f / taup;
-        Q.gx = n1.x * ig;
-        Q.gy = n1.y * ig;
-        Q.gz = n1.z * ig;
-      }
-      tri_pf[i] = Q;
-    }
+    tri_primary_records(tri[i], o, tri_p[i], tri_f[i], tri_pf[i]);
   }
   if (i < n_sph) {
     const DevSph S = sph[i];
@@ -192,6 +197,46 @@ __global__ void __launch_bounds__(256) k_prepare_groups(const SphGroups g, float
       F = sphere_filter_record(oc, dot(oc, oc) - R2, R2);
     }
     g.grp_f[i] = F;
+  }
+}
+
+// per-frame records of the triangle groups (rt_device.h TriGroups): the sorted triangles' forms,
+// and every group's / super-group's record in pre-filter form (rt_brute.h "Triangle GROUPS")
+__global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, float ox, float oy, float oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const f3 o = mk(ox, oy, oz);
+  if (i < g.n_grp * kTriGroup)
+    tri_primary_records(g.sorted[i], o, g.sorted_p[i], g.sorted_f[i], g.sorted_pf[i]);
+  if (i < g.n_grp + g.n_sup) {
+    const DevTriGroup G = g.grp[i];
+    DevTriPF Q;
+    Q.sx = Q.sy = Q.sz = Q.w = 0.f; // pad group: never within reach ...
+    Q.gx = 0x1p60f;                 // ... and never "nearly parallel" (|d.x| <= 2^-60 opens pads: harmless)
+    Q.gy = Q.gz = Q.pad = 0.f;
+    if (!(G.rgeo < 0.f)) {
+      Q.w = 2.f; // always open ...
+      Q.gx = 0.f;
+      if (G.always == 0.f) { // ... unless the static bounds are usable
+        const f3 oc = o - mk(G.cx, G.cy, G.cz);
+        const float A = (fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z);
+        const float at = A + G.rext; // >= |tvec_t|_1 for every member
+        const float R = (G.rgeo + 0x1p-21f * at) + 0x1p-60f;
+        const float R2 = R * R * 1.00001f;
+        const DevSphF F = sphere_filter_record(oc, dot(oc, oc) - R2, R2);
+        const float kappa = (((G.smax + G.b0) + G.b1 * at) + 0x1p-20f) * 1.0001f;
+        Q.sx = F.sx;
+        Q.sy = F.sy;
+        Q.sz = F.sz;
+        Q.w = F.w;
+        if (kappa < 1.f) { // else g'' = 0: always "nearly parallel"
+          const float ik = 1.f / kappa;
+          Q.gx = G.ax * ik;
+          Q.gy = G.ay * ik;
+          Q.gz = G.az * ik;
+        }
+      }
+    }
+    g.grp_pf[i] = Q;
   }
 }
 
@@ -405,11 +450,20 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   pack3<V, NV>(dir, dv);
   if (STAGE == STAGE_SMEM) {
     if constexpr (PX == 2) {
+      if (p.use_filter && p.tg.n_grp > 0) {
+        closest_tri_primary_groups(
+            SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp},
+            SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf)},
+            SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.sorted_pf)},
+            SmemFetch<TriF>{reinterpret_cast<const TriF *>(p.tg.sorted_f)},
+            SmemFetch<DevTriP>{p.tg.sorted_p}, SmemFetch<DevIdx4>{p.tg.orig}, p.tg.n_sup, dv[0], hit);
+      } else {
       const int n2 = (p.use_filter && p.n_tri >= 8) ? (p.n_tri & ~3) : 0;
       closest_tri_primary_filter(SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tri_pf)},
                                  SmemFetch<TriF>{reinterpret_cast<const TriF *>(p.tri_f)},
                                  SmemFetch<DevTriP>{p.tri_p}, n2, 0, dv[0], hit);
       closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p + n2}, p.n_tri - n2, n2, dv, hit);
+      }
     } else {
       closest_tri_primary<V, NV>(SmemFetch<DevTriP>{p.tri_p}, p.n_tri, 0, dv, hit);
     }
@@ -1076,12 +1130,16 @@ extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t ran
 // ---------------------------------------------------------------------------------------
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevTriF *tri_f, esc::DevTriPF *tri_pf, esc::DevSphP *sph_p,
-                                  esc::DevSphF *sph_f, const esc::SphGroups *sg, hipStream_t stream) {
+                                  esc::DevSphF *sph_f, const esc::SphGroups *sg,
+                                  const esc::TriGroups *tg, hipStream_t stream) {
   const int n = p->n_tri > p->n_sph ? p->n_tri : p->n_sph;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
                      tri_p, tri_f, tri_pf, p->n_tri, p->sph, sph_p, sph_f, p->n_sph, p->origin[0],
                      p->origin[1], p->origin[2]);
+  if (tg->n_grp > 0)
+    hipLaunchKernelGGL(esc::k_prepare_tri_groups, dim3((tg->n_grp * esc::kTriGroup + 255) / 256),
+                       dim3(256), 0, stream, *tg, p->origin[0], p->origin[1], p->origin[2]);
   if (sg->n_grp > 0)
     hipLaunchKernelGGL(esc::k_prepare_groups, dim3((sg->n_grp * esc::kSphGroup + 255) / 256),
                        dim3(256), 0, stream, *sg, p->origin[0], p->origin[1], p->origin[2]);

@@ -493,11 +493,12 @@ void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, 
 // whole number of `big` runs while more than one is left, and of `run`s below that, so consecutive
 // runs of `big` (super-groups) and of `run` (groups) in the result are subtrees.  Ties are broken by
 // index: the order is a function of the scene alone.
-void group_order(const std::vector<DevSph> &sph, int run, int big, std::vector<int32_t> &order) {
-  order.resize(sph.size());
+void group_order_points(const std::vector<float> &xyz, int run, int big, std::vector<int32_t> &order) {
+  const size_t n_pts = xyz.size() / 3;
+  order.resize(n_pts);
   std::iota(order.begin(), order.end(), 0);
   struct Split {
-    static void go(const std::vector<DevSph> &sph, int small, int big, int32_t *idx, size_t n) {
+    static void go(const float *xyz, int small, int big, int32_t *idx, size_t n) {
       const int run = n > (size_t)big ? big : small;
       if (n <= (size_t)small) {
         std::sort(idx, idx + n);
@@ -505,8 +506,7 @@ void group_order(const std::vector<DevSph> &sph, int run, int big, std::vector<i
       }
       float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
       for (size_t i = 0; i < n; i++) {
-        const DevSph &s = sph[(size_t)idx[i]];
-        const float c[3] = {s.cx, s.cy, s.cz};
+        const float *c = xyz + 3 * (size_t)idx[i];
         for (int a = 0; a < 3; a++) {
           lo[a] = std::min(lo[a], c[a]);
           hi[a] = std::max(hi[a], c[a]);
@@ -518,15 +518,32 @@ void group_order(const std::vector<DevSph> &sph, int run, int big, std::vector<i
       const size_t runs = (n + (size_t)run - 1) / (size_t)run;
       const size_t left = (runs / 2) * (size_t)run; // 0 < left < n since runs >= 2
       std::nth_element(idx, idx + left, idx + n, [&](int32_t a, int32_t b) {
-        const float ca = ax == 0 ? sph[(size_t)a].cx : ax == 1 ? sph[(size_t)a].cy : sph[(size_t)a].cz;
-        const float cb = ax == 0 ? sph[(size_t)b].cx : ax == 1 ? sph[(size_t)b].cy : sph[(size_t)b].cz;
+        const float ca = xyz[3 * (size_t)a + ax], cb = xyz[3 * (size_t)b + ax];
         return ca < cb || (ca == cb && a < b);
       });
-      go(sph, small, big, idx, left);
-      go(sph, small, big, idx + left, n - left);
+      go(xyz, small, big, idx, left);
+      go(xyz, small, big, idx + left, n - left);
     }
   };
-  Split::go(sph, run, big, order.data(), order.size());
+  Split::go(xyz.data(), run, big, order.data(), order.size());
+}
+
+void group_order(const std::vector<DevSph> &sph, int run, int big, std::vector<int32_t> &order) {
+  std::vector<float> xyz(3 * sph.size());
+  for (size_t i = 0; i < sph.size(); i++) {
+    xyz[3 * i + 0] = sph[i].cx;
+    xyz[3 * i + 1] = sph[i].cy;
+    xyz[3 * i + 2] = sph[i].cz;
+  }
+  group_order_points(xyz, run, big, order);
+}
+
+void group_order(const std::vector<DevTri> &tri, int run, int big, std::vector<int32_t> &order) {
+  std::vector<float> xyz(3 * tri.size());
+  for (size_t i = 0; i < tri.size(); i++)
+    for (int a = 0; a < 3; a++) // the centroid; non-finite coordinates sort somewhere, harmlessly
+      xyz[3 * i + a] = tri[i].v0[a] + (tri[i].e1[a] + tri[i].e2[a]) * (1.f / 3.f);
+  group_order_points(xyz, run, big, order);
 }
 
 // Bounding sphere of the spheres order[first .. first + count): centre = middle of the box around
@@ -557,6 +574,114 @@ DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, i
   if ((double)rf < rg) rf = std::nextafterf(rf, HUGE_VALF);
   G.rgeo = rf; // NaN / inf in, NaN / inf out: the group is then always a candidate
   return G;
+}
+
+// Static record of the triangles order[0 .. count) as one group (rt_device.h DevTriGroup), in
+// double, every bound rounded up.  Per member: centroid G, bounding radius rho around it, longest
+// edge emax, n1 = e2 x e1; a member with rho <= 2^-9.9 emax (a sliver: the pre-filter passes those
+// on unconditionally) or without a normal makes the group `always` open.
+DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *order, int count) {
+  const double u = 0x1p-24;
+  struct M {
+    double G[3], rho, nh[3], b0, b1, ext[3], a12;
+    bool bad;
+  };
+  std::vector<M> ms((size_t)count);
+  double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  bool always = false;
+  for (int i = 0; i < count; i++) {
+    const DevTri &t = tri[(size_t)order[i]];
+    M &m = ms[(size_t)i];
+    double e1[3], e2[3], s3[3], r0 = 0, r1 = 0, r2 = 0, l1 = 0, l2 = 0, a1 = 0, a2 = 0;
+    for (int a = 0; a < 3; a++) {
+      e1[a] = t.e1[a];
+      e2[a] = t.e2[a];
+      s3[a] = (e1[a] + e2[a]) / 3.0;
+      m.G[a] = (double)t.v0[a] + s3[a];
+      m.ext[a] = t.v0[a];
+      r0 += s3[a] * s3[a];
+      r1 += (e1[a] - s3[a]) * (e1[a] - s3[a]);
+      r2 += (e2[a] - s3[a]) * (e2[a] - s3[a]);
+      l1 += e1[a] * e1[a];
+      l2 += e2[a] * e2[a];
+      a1 += std::fabs(e1[a]);
+      a2 += std::fabs(e2[a]);
+    }
+    m.rho = std::sqrt(std::max(r0, std::max(r1, r2))) * 1.00002;
+    m.a12 = a1 + a2;
+    const double emax = std::sqrt(std::max(l1, l2));
+    const double n1[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2],
+                          e2[0] * e1[1] - e2[1] * e1[0]};
+    const double nn = std::sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+    m.bad = !(m.rho > 0x1.2p-10 * emax) || !(nn > 0.0) || !std::isfinite(nn) || !std::isfinite(m.rho);
+    if (m.bad) {
+      always = true;
+      continue;
+    }
+    for (int a = 0; a < 3; a++) m.nh[a] = n1[a] / nn;
+    // tau = 3.2u (10.04 |tv||e2| + 5.04 |tv||e1| + 20.1 |e1||e2|) emax / rho (1-norms), rt_brute.h
+    const double k = 3.2 * u * emax / (m.rho / 1.00002) / nn * 1.0001;
+    m.b1 = k * (10.04 * a2 + 5.04 * a1);
+    m.b0 = k * 20.1 * a1 * a2;
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::min(lo[a], m.G[a] - 2.0 * m.rho);
+      hi[a] = std::max(hi[a], m.G[a] + 2.0 * m.rho);
+    }
+  }
+  DevTriGroup g;
+  std::memset(&g, 0, sizeof(g));
+  g.always = 1.f;
+  g.rgeo = 0.f;
+  if (always || count == 0) { // the sweeps open it whatever the ray: the other fields are unused
+    if (count > 0) {
+      g.cx = tri[(size_t)order[0]].v0[0];
+      g.cy = tri[(size_t)order[0]].v0[1];
+      g.cz = tri[(size_t)order[0]].v0[2];
+    }
+    return g;
+  }
+  auto up = [](double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, HUGE_VALF);
+    return f;
+  };
+  g.cx = (float)(0.5 * (lo[0] + hi[0]));
+  g.cy = (float)(0.5 * (lo[1] + hi[1]));
+  g.cz = (float)(0.5 * (lo[2] + hi[2]));
+  const double C[3] = {g.cx, g.cy, g.cz};
+  double rg = 0, rext = 0, b0 = 0, b1 = 0, ax[3] = {0, 0, 0};
+  for (const M &m : ms) {
+    const double d[3] = {m.G[0] - C[0], m.G[1] - C[1], m.G[2] - C[2]};
+    rg = std::max(rg, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 2.0 * m.rho);
+    rext = std::max(rext, std::fabs(m.ext[0] - C[0]) + std::fabs(m.ext[1] - C[1]) +
+                              std::fabs(m.ext[2] - C[2]) + m.a12);
+    b0 = std::max(b0, m.b0);
+    b1 = std::max(b1, m.b1);
+    const double sgn = (m.nh[0] * ms[0].nh[0] + m.nh[1] * ms[0].nh[1] + m.nh[2] * ms[0].nh[2]) < 0 ? -1.0 : 1.0;
+    for (int a = 0; a < 3; a++) ax[a] += sgn * m.nh[a];
+  }
+  const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  if (!(an > 1e-3) || !std::isfinite(rg) || !std::isfinite(rext)) return g; // no cone: always open
+  for (int a = 0; a < 3; a++) ax[a] /= an;
+  g.ax = (float)ax[0];
+  g.ay = (float)ax[1];
+  g.az = (float)ax[2];
+  // sines against the axis AS STORED (fp32, not exactly unit: normalise in double)
+  const double fa[3] = {g.ax, g.ay, g.az};
+  const double fn = std::sqrt(fa[0] * fa[0] + fa[1] * fa[1] + fa[2] * fa[2]);
+  double smax = 0;
+  for (const M &m : ms) {
+    const double c[3] = {fa[1] * m.nh[2] - fa[2] * m.nh[1], fa[2] * m.nh[0] - fa[0] * m.nh[2],
+                         fa[0] * m.nh[1] - fa[1] * m.nh[0]};
+    smax = std::max(smax, std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) / fn);
+  }
+  g.smax = up(smax * (1.0 + 1e-6) + 1e-7);
+  g.rgeo = up(rg * (1.0 + 0x1p-40));
+  g.rext = up(rext * (1.0 + 1e-6));
+  g.b0 = up(b0);
+  g.b1 = up(b1);
+  g.always = 0.f;
+  return g;
 }
 
 } // namespace esc
