@@ -1154,6 +1154,80 @@ DEVINL void anyhit_tri_filter(FetchP recp, FetchF recf, FetchE rece, int n, int 
   }
 }
 
+// Triangle GROUPS for the shadow rays of the last light ("Triangle GROUPS" above; any occluder
+// decides the ray there, so the order of the tests is free).  Group records have the form of the
+// pre-filter's pair records: the bounding sphere in q' form with R = rgeo + 8u at, the cone axis
+// over kappa' = (smax + b0 + b1 at + 2^-20) * 1.0001, at = rho_max + |C - g|_1 + rext >= |O - v0_t|_1
+// for every member and every ray that starts within rho_max of g (host, rt_capi.cpp commit());
+// rays from further out (`far`) open everything.  4 super-groups per step; an opened super-group
+// costs two steps over its 8 groups, an opened group runs anyhit_tri_filter over its 8 triangles.
+// Returns the filter tests this wave swept (4 per step at any level); n_open counts the 8-record
+// openings each ray itself needed.
+constexpr int kTriGroupExitSteps = 4; // exit check every 16 super-groups
+template <typename FetchP, typename FetchF, typename FetchE>
+DEVINL int anyhit_tri_groups_filter(FetchP recu, FetchP recg, FetchP recp, FetchF recf, FetchE rece,
+                                    int n_sup, int base, f3 o, f3 L, const RayF &rs, const RayTF &rf,
+                                    bool far, Any (&a)[1], int &n_open) {
+  int swept = 0;
+  auto members = [&](int g) { // sorted triangles [8 g, 8 g + 8) = pair records [4 g, 4 g + 4)
+    anyhit_tri_filter(FetchP{recp.p + 4 * g}, FetchF{recf.p + 4 * g}, FetchE{rece.p + 8 * g}, kTriGroup,
+                      base + 8 * g, o, L, rs, rf, far, a);
+  };
+  // 2 pair records = 4 bounding spheres + cones: wave-uniform mask of the ones a LIVE lane may touch
+  auto open_mask = [&](const TriPairPF(&R)[2]) -> uint32_t {
+    v2f q[2], g[2];
+    tripair2_any_prefilter_pk(R, rs, q, g);
+    const bool live = a[0].tb > 0.f;
+    const int mq = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                       __float_as_int(q[1].y));
+    float mn = 2.f;
+    asm("v_min3_f32 %0, %0, |%1|, |%2|\n\tv_min3_f32 %0, %0, |%3|, |%4|"
+        : "+v"(mn)
+        : "v"(g[0].x), "v"(g[0].y), "v"(g[1].x), "v"(g[1].y));
+    uint32_t mask = 0;
+    if (ANY_LANE_RARE(live && ((mq >= 0) | (mn <= 1.f) | far))) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool c0 = live && (far || __float_as_int(q[j].x) >= 0 || fabsf(g[j].x) <= 1.f);
+        const bool c1 = live && (far || __float_as_int(q[j].y) >= 0 || fabsf(g[j].y) <= 1.f);
+        if (__builtin_amdgcn_ballot_w64(c0)) mask |= 1u << (2 * j);
+        if (__builtin_amdgcn_ballot_w64(c1)) mask |= 2u << (2 * j);
+        n_open += (int)c0 + (int)c1;
+      }
+    }
+    return mask;
+  };
+  auto groups = [&](int s) { // the 8 groups = 4 pair records of super-group s, 2 records at a time
+    for (int half = 0; half < 2; ++half) {
+      const TriPairPF G[2] = {recg(4 * s + 2 * half), recg(4 * s + 2 * half + 1)};
+      uint32_t mask = open_mask(G);
+      swept += 4;
+      while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        members(8 * s + 4 * half + j);
+        swept += kTriGroup;
+      }
+    }
+  };
+  for (int s0 = 0; s0 < n_sup; s0 += 4 * kTriGroupExitSteps) {
+    if (!__builtin_amdgcn_ballot_w64(a[0].tb > 0.f)) return swept;
+    const int m = min(4 * kTriGroupExitSteps, n_sup - s0); // multiple of 4
+    swept += m;
+    // one register set, as in anyhit_tri_filter: the slow paths behind it leave no room for two
+    for (int s = 0; s < m; s += 4) {
+      const TriPairPF U[2] = {recu((s0 + s) >> 1), recu(((s0 + s) >> 1) + 1)};
+      uint32_t mask = open_mask(U);
+      while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        groups(s0 + s + j);
+      }
+    }
+  }
+  return swept;
+}
+
 template <typename V, int NV, int NB>
 DEVINL void test_sph_any(const DevSph (&s)[NB], int idx, const V3<V> (&o)[NV],
                          const V3<V> (&L)[NV], Any (&a)[NV * lanes_of<V>::n]) {

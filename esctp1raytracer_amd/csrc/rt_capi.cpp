@@ -1428,14 +1428,16 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   }();
   const int want = (opts->flags & ESC_RENDER_SHADE_QUEUE) ? 2
                    : (opts->flags & ESC_RENDER_SHADE_FUSED) ? 1 : shade_env;
-  // a single light's shadow rays sweep the sphere GROUPS in the fused form (rt_device.h SphGroups):
-  // about an eighth of the tests
-  const int64_t eff_sph =
-      (p.use_filter && p.sg.n_grp > 0 && p.n_lights == 1) ? p.n_sph / esc::kSphGroup : p.n_sph;
+  // A single light's shadow rays sweep the primitive GROUPS (rt_device.h SphGroups / TriGroups),
+  // which only the fused form does: a grouped table then counts as nothing here.  With several
+  // lights all but the last sweep the whole list in index order, and the rule is the old one.
+  const bool one_light_groups = p.use_filter && p.n_lights == 1;
+  const int64_t eff_sph = (one_light_groups && p.sg.n_grp > 0) ? 0 : p.n_sph;
+  const int64_t eff_tri = (one_light_groups && p.tg.n_grp > 0) ? 0 : p.n_tri;
   const bool queue_form =
       stage == 1 && p.shadows && p.n_lights > 0 && want != 1 &&
       (want == 2 || opts->stage == ESC_STAGE_AUTO) &&
-      (want == 2 || ((int64_t)p.n_tri + eff_sph >= kQueueMinPrims &&
+      (want == 2 || (eff_tri + eff_sph >= kQueueMinPrims &&
                      (int64_t)n_local_rows * W >= kQueueMinPixels));
   if (queue_form) {
     int rc = render_shade_queue(ctx, p, px, timed ? ctx->ev[1] : nullptr);

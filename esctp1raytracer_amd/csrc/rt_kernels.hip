@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
 // waves per SIMD asked of the register allocator: 6 (80 VGPRs) measured best for the SMEM and BVH
 // variants (5 and 4 were 1 % slower / no different); the LDS variant's 46 KB of LDS allow 4
 template <int STAGE>
-__global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const RenderParams p) {
+__global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (STAGE == STAGE_SMEM ? 5 : 6)) k_shade(const RenderParams p) {
   typedef float V;
   constexpr int NV = 1;
   constexpr int TW = 32;
@@ -614,7 +614,8 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
   for (int li = 0; li < p.n_lights; ++li) {
     const DevLight Lt = p.lights[li];
     Any a[1];
-    int grp_open = -1; // >= 0: this light swept the sphere groups; groups opened for this ray
+    int grp_open = 0; // 8-record openings of group sweeps this ray needed (counters only)
+    bool tri_groups = false, sph_groups = false; // this light swept triangle / sphere groups
     f3 ro = N, rL = N; // shadow-ray origin (main.cpp:757 `hit`) and unit direction
     f3 lP = N;         // the light sample point and its index (light bins, ESC_STAGE_BVH)
     int lpt = 0;
@@ -694,19 +695,22 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         // k0 then counts pair records of the sorted table, 4 per group, segments whole steps
         const bool grp = (li == p.n_lights - 1) && p.use_filter && p.sg.n_grp > 0;
         const int n_rec = grp ? p.sg.n_grp * (kSphGroup / 2) : (p.n_sph + 1) >> 1;
-        int k0 = 0, seg = kSegTris; // triangles first (index order)
+        // ... and the triangle GROUPS (rt_device.h TriGroups): k0 counts sorted slots, 8 per group
+        const bool tgrp = (li == p.n_lights - 1) && p.use_filter && p.tg.n_grp > 0;
+        const int n_tri_sweep = tgrp ? p.tg.n_grp * kTriGroup : p.n_tri;
+        int k0 = 0, seg = tgrp ? kSegGroupPairs : kSegTris; // triangles first (index order)
         bool in_tris = p.n_tri > 0;
         const int seg_sph = grp ? kSegGroupPairs : kSegSphPairs;
         if (!in_tris) seg = seg_sph;
         for (int sg = 0;; ++sg) {
-          if (in_tris && k0 >= p.n_tri) {
+          if (in_tris && k0 >= n_tri_sweep) {
             in_tris = false;
             k0 = 0;
             seg = seg_sph;
             sg = 0;
           }
           if (!in_tris && k0 >= n_rec) break;
-          const int n_here = min(seg, (in_tris ? p.n_tri : n_rec) - k0);
+          const int n_here = min(seg, (in_tris ? n_tri_sweep : n_rec) - k0);
           const int n_live = repack_rays(R, tid);
           if (n_live == 0) break; // workgroup-uniform
           if (wave * 64 < n_live) { // otherwise this wave sits the segment out
@@ -719,7 +723,22 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
             aa[0].kocc = -1;
             const f3 so = mk(R.ox[rs], R.oy[rs], R.oz[rs]);
             const f3 sL = mk(R.lx[rs], R.ly[rs], R.lz[rs]);
-            if (in_tris) {
+            if (in_tris && tgrp) {
+              bool far;
+              const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
+              const RayF rs = make_ray_filter(so, sL, p.shadow_center);
+              int n_open = 0;
+              // k0 sorted slots in = k0 / 8 groups = k0 / 64 super-groups; two per pair record
+              n_swept += anyhit_tri_groups_filter(
+                  SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) +
+                                       (p.tg.n_grp >> 1) + (k0 >> 7)},
+                  SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) + (k0 >> 4)},
+                  SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.sorted2_pf) + (k0 >> 1)},
+                  SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tg.sorted2_f) + (k0 >> 1)},
+                  SmemFetch<DevTri>{p.tg.sorted + k0}, n_here >> 6, k0, so, sL, rs, rt, far, aa,
+                  n_open);
+              if (rr >= 0 && n_open) R.n_open[rr] += n_open;
+            } else if (in_tris) {
               const V3<V> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
               n_swept += n_here; // upper bound: exits inside a segment are not subtracted
               if (p.use_filter && n_here >= 8) { // k0 is even: segment lengths are
@@ -770,7 +789,9 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         __syncthreads();
         a[0].kocc = R.kocc[tid];
         a[0].tocc = R.tocc[tid];
-        if (grp) grp_open = R.n_open[tid];
+        if (grp || tgrp) grp_open = R.n_open[tid];
+        tri_groups = tgrp;
+        sph_groups = grp;
         rL = mk(R.lx[tid], R.ly[tid], R.lz[tid]); // not kept live across the segments
         N = mk(R.keep[0][tid], R.keep[1][tid], R.keep[2][tid]);
         r = R.keep[3][tid]; g = R.keep[4][tid]; b = R.keep[5][tid];
@@ -803,14 +824,17 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : 6) k_shade(const
         n_shadow += 1u;
         // tests occlusion() runs for this ray: up to and including its first occluder
         if (STAGE != STAGE_BVH) {
-          if (grp_open >= 0 && !(a[0].kocc >= 0 && a[0].kocc < p.n_tri)) {
-            // group sweep: every triangle, the super-groups up to the occluder's (or all), 8 more
-            // filter tests per super-group / group this ray had opened
-            const int s_tested = (a[0].kocc >= 0) ? ((a[0].kocc - p.n_tri) >> 6) + 1 : p.sg.n_sup;
-            n_any += (unsigned)(p.n_tri + s_tested + 8 * grp_open);
-          } else {
-            n_any += (a[0].kocc >= 0) ? (unsigned)(a[0].kocc + 1) : (unsigned)(p.n_tri + p.n_sph);
-          }
+          // index-order sweeps: up to and including the occluder.  Group sweeps: the super-groups
+          // up to the occluder's (or all), 8 more filter tests per super-group / group this ray
+          // had opened.
+          const int k = a[0].kocc;
+          const bool by_tri = k >= 0 && k < p.n_tri;
+          unsigned cnt = tri_groups ? (unsigned)(by_tri ? (k >> 6) + 1 : p.tg.n_sup)
+                                    : (unsigned)(by_tri ? k + 1 : p.n_tri);
+          if (!by_tri)
+            cnt += sph_groups ? (unsigned)(k >= 0 ? ((k - p.n_tri) >> 6) + 1 : p.sg.n_sup)
+                              : (unsigned)(k >= 0 ? k - p.n_tri + 1 : p.n_sph);
+          n_any += cnt + 8u * (unsigned)grp_open;
         }
       }
       if (p.shadows && a[0].kocc >= 0) {

@@ -484,15 +484,18 @@ def test_icosphere_twins_of_the_sphere_configs(esc, renderer, config, n, subdiv,
     assert 0 < rc["hit_pixels"] < W * H
     renderer.upload(ol.scene_to_product(tw))
     cam = esc.Camera.for_image(eye, look, W, H)
-    for stage in (esc.ESC_STAGE_SMEM, esc.ESC_STAGE_LDS, esc.ESC_STAGE_BVH):
+    # brute force: default order (triangle groups, csrc/rt_device.h TriGroups) and index order,
+    # whose any-hit count is the reference's
+    for stage, flags in ((esc.ESC_STAGE_SMEM, 0), (esc.ESC_STAGE_SMEM, esc.ESC_RENDER_INDEX_ORDER),
+                         (esc.ESC_STAGE_LDS, 0), (esc.ESC_STAGE_BVH, 0)):
         renderer.reset_counters()
-        gpu, u8 = renderer.render(cam, W, H, want_u8=True, shadows=shadows, stage=stage)
+        gpu, u8 = renderer.render(cam, W, H, want_u8=True, shadows=shadows, stage=stage, flags=flags)
         cnt = renderer.counters()
-        assert_bit_equal(gpu, ref, f"twin/{config}/stage{stage}")
+        assert_bit_equal(gpu, ref, f"twin/{config}/stage{stage}/flags{flags}")
         assert np.array_equal(u8, ol.oracle_quantise(ref))
         for k in ("primary_rays", "hit_pixels", "shadow_rays"):
             assert cnt[k] == rc[k]
-        if stage != esc.ESC_STAGE_BVH:
+        if stage == esc.ESC_STAGE_LDS or flags == esc.ESC_RENDER_INDEX_ORDER:
             assert cnt["anyhit_tests"] == rc["anyhit_tests"]
 
 
