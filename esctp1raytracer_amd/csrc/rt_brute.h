@@ -754,6 +754,19 @@ DEVINL void closest_tri_primary_filter(FetchP recp, FetchF recf, FetchE rece, in
 //   |d . a| <= |d . n_t| + |d| smax.  The record holds a / kappa', kappa' = (smax + b0 + b1 (A + rext)
 //   + 2^-20) * 1.0001, so |g''| <= 1 for the FMA chain (its own 3.01u |a|_1 / kappa' sits inside
 //   the 2^-20).  kappa' >= 1 (no useful cone), a sliver among the members: the group is always open.
+//  (P) Primary rays only: (E_t) can carry an accept only when the camera is nearly IN the member's
+//   plane.  With tvec = p + h n_t (p in the plane), un* = tvec . (d x e2) = lambda (d . n_t) + h d . (e2 x n_t)
+//   and vn* = d . (tvec x e1) = mu (d . n_t) + h d . (n_t x e1), |lambda| <= |e2||tvec|, |mu| <= |e1||tvec|.
+//   An accept has |un|, |vn| <= |det| (1 + 4u), so with the reference's error bounds eu, ev, ed and
+//   |det*| < tau:  |un*| < U := (tau + ed)(1 + 4u) + eu,  |vn*| < V := (tau + ed)(1 + 4u) + ev, hence
+//   |h| |d . w2| <= U / |e2| + |tvec| tau / |n1|  and  |h| |d . w1| <= V / |e1| + |tvec| tau / |n1|  for the
+//   in-plane unit vectors w1, w2 across e1, e2.  They enclose the triangle's angle phi, so one of
+//   |d . w_i| is at least |d_par| min(sin, cos)(phi / 2) >= 0.99 gamma, gamma = |n1| / (2 |e1||e2|), as long
+//   as |d . n_t| < 0.1:   |h| <= H_t := [max(V / |e1|, U / |e2|) + |tvec| tau / |n1|] / (0.99 gamma),
+//   a few hundredths of a unit on c5.  The camera is one point per frame: k_prepare_tri_groups
+//   evaluates |h| <= H_t for every member of every group and super-group (tri_escape_possible), and
+//   where no member passes, no ray of the frame can be accepted through (E_t) by any of them:
+//   the record's cone part is switched off.  Only groups with a member seen edge-on keep it.
 // A member accept therefore opens its group and super-group; inside an opened group the per-triangle
 // pre-filter, the filter and the reference arithmetic run as before.  Order: as for the sphere
 // groups, an equal closest t goes to the lower ORIGINAL index.

@@ -1527,6 +1527,26 @@ int esc_assemble_strips(esc_context *ctx, const void *d_gathered, int32_t n_rank
   return ESC_OK;
 }
 
+int esc_tri_group_record(const float *v0e1e2, int32_t count, float record[12]) {
+  if (!v0e1e2 || !record || count <= 0) {
+    set_error("esc_tri_group_record: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  std::vector<esc::DevTri> tri((size_t)count);
+  std::vector<int32_t> order((size_t)count);
+  for (int32_t i = 0; i < count; i++) {
+    std::memset(&tri[(size_t)i], 0, sizeof(esc::DevTri));
+    std::memcpy(tri[(size_t)i].v0, v0e1e2 + 9 * (size_t)i, 12);
+    std::memcpy(tri[(size_t)i].e1, v0e1e2 + 9 * (size_t)i + 3, 12);
+    std::memcpy(tri[(size_t)i].e2, v0e1e2 + 9 * (size_t)i + 6, 12);
+    order[(size_t)i] = i;
+  }
+  const esc::DevTriGroup g = esc::tri_group_bounds(tri, order.data(), count);
+  static_assert(sizeof(g) == 48, "12 floats");
+  std::memcpy(record, &g, sizeof(g));
+  return ESC_OK;
+}
+
 int esc_queue_schedule(int32_t n_triangles, int32_t n_spheres, int32_t *segments,
                        int32_t capacity) {
   if (n_triangles < 0 || n_spheres < 0 || capacity < 0 || (capacity && !segments)) {

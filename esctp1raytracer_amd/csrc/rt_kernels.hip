@@ -200,6 +200,35 @@ __global__ void __launch_bounds__(256) k_prepare_groups(const SphGroups g, float
   }
 }
 
+// (P) of rt_brute.h "Triangle GROUPS": may a ray from the camera o be accepted by triangle T through
+// the pre-filter's "nearly parallel" escape at all?  Only if the camera lies within H of T's plane.
+// Everything in fp32 from T's own record; 1 % + 16u |tvec| on top of H cover the roundings, and
+// every doubtful case (a sliver, a non-finite value) answers yes.
+DEVINL bool tri_escape_possible(const DevTri &T, f3 o) {
+  const float u = 0x1p-24f;
+  const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+  const f3 tv = o - ld3(T.v0);
+  const f3 n1 = cross(e2, e1);
+  const float nn = sqrtf(dot(n1, n1));
+  const float a1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z);
+  const float a2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
+  const float at = (fabsf(tv.x) + fabsf(tv.y)) + fabsf(tv.z);
+  const float l1 = sqrtf(dot(e1, e1)), l2 = sqrtf(dot(e2, e2));
+  const f3 s3 = (e1 + e2) * (1.f / 3.f);
+  const float rho = sqrtf(fmaxf(fmaxf(dot(s3, s3), dot(e1 - s3, e1 - s3)), dot(e2 - s3, e2 - s3)));
+  const float emax = fmaxf(l1, l2);
+  if (!(rho > 0x1.2p-10f * emax) || !(nn > 0.f)) return true; // sliver / no normal
+  const float p12 = a1 * a2;
+  const float k = 3.2f * u * emax / rho * 1.0001f;
+  const float tau = k * ((10.04f * a2 + 5.04f * a1) * at + 20.1f * p12);
+  if (!(tau < 0.1f * nn)) return true; // |d . n| < 0.1 is part of the argument
+  const float ted = (tau + 10.05f * u * p12) * (1.f + 4.f * u);
+  const float U = ted + 10.04f * u * at * a2, V = ted + 5.04f * u * at * a1;
+  const float H = (fmaxf(V / l1, U / l2) + at * tau / nn) * (2.f * l1 * l2 / nn) * (1.f / 0.99f);
+  const float h = fabsf(dot(tv, n1)) / nn;
+  return !(h > H * 1.01f + 0x1p-20f * at); // NaN: yes
+}
+
 // per-frame records of the triangle groups (rt_device.h TriGroups): the sorted triangles' forms,
 // and every group's / super-group's record in pre-filter form (rt_brute.h "Triangle GROUPS")
 __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, float ox, float oy, float oz) {
@@ -228,7 +257,21 @@ __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, f
         Q.sy = F.sy;
         Q.sz = F.sz;
         Q.w = F.w;
-        if (kappa < 1.f) { // else g'' = 0: always "nearly parallel"
+        // (P): no member can be accepted through the escape unless the camera is within H_t of
+        // its plane -- checked member by member (8 or 64 of them) for this frame's camera
+        const int per = (i < g.n_grp) ? kTriGroup : kTriGroup * kTriSuper;
+        const int first = ((i < g.n_grp) ? i : (i - g.n_grp)) * per;
+        bool possible = false;
+        for (int m = 0; m < per && !possible; ++m) {
+          const DevTri T = g.sorted[first + m];
+          const bool pad_slot = T.e1[0] == 0.f && T.e1[1] == 0.f && T.e1[2] == 0.f && T.e2[0] == 0.f &&
+                                T.e2[1] == 0.f && T.e2[2] == 0.f; // det == 0 exactly: rejected
+          possible = !pad_slot && tri_escape_possible(T, o);
+        }
+        const bool no_escape = !possible;
+        if (no_escape) {
+          Q.gx = 0x1p60f; // |g''| <= 1 only for |d.x| <= 2^-60: a needless opening at worst
+        } else if (kappa < 1.f) { // else g'' = 0: always "nearly parallel"
           const float ik = 1.f / kappa;
           Q.gx = G.ax * ik;
           Q.gy = G.ay * ik;

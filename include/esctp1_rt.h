@@ -343,6 +343,12 @@ int esc_scene_build_accel(const esc_scene *scene, const float origin[3], int32_t
  * tests: every primitive must be covered exactly once, in order. */
 int esc_queue_schedule(int32_t n_triangles, int32_t n_spheres, int32_t *segments,
                        int32_t capacity);
+
+/* Host only, for inspection and tests: the static record of `count` triangles taken as ONE group
+ * of the brute-force kernels' triangle groups (csrc/rt_device.h DevTriGroup): v0e1e2 holds 9
+ * floats per triangle (vert0, vert1 - vert0, vert2 - vert0); record receives 12 floats:
+ * centre xyz, rgeo, cone axis xyz, smax, rext, b0, b1, always.  Returns 0 or a negative error. */
+int esc_tri_group_record(const float *v0e1e2, int32_t count, float record[12]);
 /* ms[0] = k_primary, ms[1] = k_shade of the last frame rendered with ESC_RENDER_TIME_KERNELS
  * (waits for that frame).  This is how bench.py prices each kernel against its own roof. */
 int esc_last_kernel_ms(esc_context *ctx, float ms[2]);

@@ -615,3 +615,147 @@ def test_triangle_shadow_prefilter_never_rejects_a_reference_candidate(scale, si
     assert ref_ok.sum() > n // 16
     missed = ref_ok & ~passed
     assert not missed.any(), f"{int(missed.sum())} reference candidates rejected by the pre-filter"
+
+
+# ------------------------------------------------------------------ triangle groups
+def _escape_possible(o, v0, e1, e2):
+    """numpy mirror of k_prepare_tri_groups' tri_escape_possible (fp32), one camera per row"""
+    u = f32(2.0 ** -24)
+    tv = [f32(o[:, i] - v0[:, i]) for i in range(3)]
+    n1 = ref_cross(e2[:, 0], e2[:, 1], e2[:, 2], e1[:, 0], e1[:, 1], e1[:, 2])
+
+    def d3(a, b):
+        return ref_dot(a[0], a[1], a[2], b[0], b[1], b[2])
+    nn = np.sqrt(d3(n1, n1), dtype=f32)
+    a1, a2, at = l1(*e1.T), l1(*e2.T), l1(*tv)
+    len1, len2 = np.sqrt(d3(e1.T, e1.T), dtype=f32), np.sqrt(d3(e2.T, e2.T), dtype=f32)
+    third = f32(1.0) / f32(3.0)
+    s3 = [f32(f32(e1[:, i] + e2[:, i]) * third) for i in range(3)]
+    e1s = [f32(e1[:, i] - s3[i]) for i in range(3)]
+    e2s = [f32(e2[:, i] - s3[i]) for i in range(3)]
+    rho = np.sqrt(np.maximum(np.maximum(d3(s3, s3), d3(e1s, e1s)), d3(e2s, e2s)), dtype=f32)
+    emax = np.maximum(len1, len2)
+    with np.errstate(all="ignore"):
+        yes = ~(rho > f32(1.125 * 2.0 ** -10) * emax) | ~(nn > 0)
+        p12 = f32(a1 * a2)
+        k = f32(f32(f32(f32(3.2) * u) * emax) / rho * f32(1.0001))
+        tau = f32(k * f32(f32(f32(f32(10.04) * a2) + f32(f32(5.04) * a1)) * at + f32(f32(20.1) * p12)))
+        yes |= ~(tau < f32(f32(0.1) * nn))
+        ted = f32(f32(tau + f32(f32(f32(10.05) * u) * p12)) * f32(f32(1) + f32(4) * u))
+        U = f32(ted + f32(f32(f32(f32(10.04) * u) * at) * a2))
+        V = f32(ted + f32(f32(f32(f32(5.04) * u) * at) * a1))
+        H = f32(f32(f32(np.maximum(f32(V / len1), f32(U / len2)) + f32(f32(at * tau) / nn)) *
+                    f32(f32(f32(f32(2) * len1) * len2) / nn)) * f32(f32(1) / f32(0.99)))
+        h = f32(np.abs(d3(tv, n1)) / nn)
+        yes |= ~(h > f32(f32(H * f32(1.01)) + f32(f32(2.0 ** -20) * at)))
+    return yes
+
+
+@pytest.mark.parametrize("scale,size,with_slab", [(1.0, 0.3, True), (30.0, 0.1, True), (30.0, 3.0, True),
+                                                  (1000.0, 0.05, True), (30.0, 3.0, False)])
+def test_triangle_primary_group_never_rejects_a_member_candidate(scale, size, with_slab):
+    """rt_device.h TriGroups, primary rays: the group record (bounding sphere of the members'
+    pre-filter spheres OR "nearly parallel to the cone of their normals", the cone part switched
+    off when the camera is in no member's slab -- statement (P) of rt_brute.h) against the
+    reference accept of a member.  Groups of 8 triangles off a bumpy patch; cameras anywhere and
+    (half of them) a hair off a member's plane, rays that hug the member's edges or run nearly in
+    its plane.  Static bounds come from the library (esc_tri_group_record, host only); the
+    per-frame record is mirrored here statement by statement.  with_slab=False drops (P)'s
+    condition and switches every cone off: the same rays must then lose candidates -- the
+    scenario has the power to see the escape missing (with edges of a few units: for small
+    triangles a det of rounding noise, ~u |e1||e2|, never clears the reference's absolute
+    |det| > FLT_EPSILON)."""
+    import ctypes as C
+    from esctp1raytracer_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(int(scale * 3 + size * 100))
+    n_grp, per = 6000, 60
+    # 8 triangles per group: a 2 x 2 quad patch of y = bump(x, z), randomly rotated and placed
+    gx, gz = np.meshgrid(np.arange(3), np.arange(3), indexing="ij")
+    rec = np.zeros((n_grp, 12), f32)
+    V0 = np.zeros((n_grp, 8, 3), f32)
+    E1 = np.zeros((n_grp, 8, 3), f32)
+    E2 = np.zeros((n_grp, 8, 3), f32)
+    for g in range(n_grp):
+        ph = rng.uniform(0, 6.3, 2)
+        amp = rng.choice([0.0, 0.05, 0.5])  # flat groups (coplanar members) included
+        P = np.stack([gx * size, amp * size * np.sin(gx * 0.8 + ph[0]) * np.cos(gz * 0.7 + ph[1]), gz * size], -1)
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        P = P @ Q.T + rng.uniform(-1, 1, 3) * scale
+        a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+        tri = np.concatenate([np.stack([a, b, c], 2).reshape(-1, 3, 3), np.stack([a, c, d], 2).reshape(-1, 3, 3)])
+        tri = tri.astype(f32)
+        V0[g], E1[g], E2[g] = tri[:, 0], f32(tri[:, 1] - tri[:, 0]), f32(tri[:, 2] - tri[:, 0])
+        buf = np.ascontiguousarray(np.concatenate([V0[g], E1[g], E2[g]], axis=1), f32)
+        assert lib.esc_tri_group_record(buf.ctypes.data_as(C.POINTER(C.c_float)), 8,
+                                        rec[g].ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert (rec[:, 11] == 0).all()  # none is `always`
+    n = n_grp * per
+    gi = np.repeat(np.arange(n_grp), per)
+    mi = rng.integers(0, 8, n)
+    v0, e1, e2 = V0[gi, mi], E1[gi, mi], E2[gi, mi]
+    nrm = np.cross(e1.astype(np.float64), e2.astype(np.float64))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    # cameras: random; half of them moved to within a hair of the member's plane
+    o = rng.uniform(-1, 1, (n, 3)) * scale * 1.5
+    inplane = rng.uniform(size=n) < 0.5
+    hgt = ((o - v0) * nrm).sum(1, keepdims=True)
+    dist = np.linalg.norm(o - v0, axis=1, keepdims=True)
+    o = np.where(inplane[:, None], o - nrm * hgt + nrm * dist * rng.choice([-1, 1], (n, 1)) *
+                 10.0 ** rng.uniform(-9, -3, (n, 1)), o).astype(f32)
+    d = rays_near_edges(rng, o, v0, e1, e2, n)
+    graze = rng.uniform(size=n) < 0.5
+    dd = d.astype(np.float64)
+    dd = dd - nrm * (dd * nrm).sum(1, keepdims=True) * (1 - 10.0 ** rng.uniform(-9, -2, (n, 1)))
+    d = np.where(graze[:, None], unit(dd), d)
+    # a third of the rays: camera AND ray in the member's plane, close by, the line passing the
+    # whole group at 1.2 .. 3 of its radii -- only the escape can let these through, and the
+    # reference does accept some of them (everything it computes there is rounding noise)
+    G = rec[gi]
+    Cg, rg = G[:, 0:3].astype(np.float64), G[:, 3:4].astype(np.float64)
+    miss = rng.uniform(size=n) < 0.34
+    t1 = np.cross(nrm, rng.normal(size=(n, 3)))
+    t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    t2 = np.cross(nrm, t1)
+    Cp = Cg - nrm * ((Cg - v0) * nrm).sum(1, keepdims=True)       # C projected into the plane
+    om = Cp + t1 * rg * rng.uniform(3, 10, (n, 1))                 # camera in the plane
+    aim = Cp + t2 * rg * rng.uniform(1.2, 3, (n, 1)) * rng.choice([-1, 1], (n, 1))
+    o = np.where(miss[:, None], om.astype(f32), o)
+    d = np.where(miss[:, None], unit(aim - o.astype(np.float64)), d)
+    dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+    # reference accept of the member
+    tv = [f32(o[:, i] - v0[:, i]) for i in range(3)]
+    qv = ref_cross(*tv, e1[:, 0], e1[:, 1], e1[:, 2])
+    pv = ref_cross(dx, dy, dz, e2[:, 0], e2[:, 1], e2[:, 2])
+    det = ref_dot(e1[:, 0], e1[:, 1], e1[:, 2], *pv)
+    ref_ok = uv_accept(det, ref_dot(*tv, *pv), ref_dot(*qv, dx, dy, dz))
+    # k_prepare_tri_groups, fp32 statement by statement
+    oc = [f32(o[:, i] - G[:, i]) for i in range(3)]
+    A = l1(*oc)
+    at = f32(A + G[:, 8])
+    R = f32(f32(G[:, 3] + f32(f32(2.0 ** -21) * at)) + f32(2.0 ** -60))
+    R2 = f32(f32(R * R) * f32(1.00001))
+    sx, sy, sz, w = _scaled_record(oc[0], oc[1], oc[2], f32(ref_dot(*oc, *oc) - R2), R2)
+    kappa = f32(f32(f32(f32(G[:, 7] + G[:, 9]) + f32(G[:, 10] * at)) + f32(2.0 ** -20)) * f32(1.0001))
+    possible = np.zeros(n, bool)
+    if with_slab:
+        for m in range(8):
+            possible |= _escape_possible(o, V0[gi, m], E1[gi, m], E2[gi, m])
+    cone = possible & (kappa < 1)
+    ik = f32(f32(1) / kappa)
+    gxv = np.where(cone, f32(G[:, 4] * ik), np.where(possible, f32(0), f32(2.0 ** 60)))
+    gyv = np.where(cone, f32(G[:, 5] * ik), f32(0))
+    gzv = np.where(cone, f32(G[:, 6] * ik), f32(0))
+    b = fma(sz, dz, fma(sy, dy, fma(sx, dx, w)))
+    gg = fma(gzv, dz, fma(gyv, dy, f32(gxv * dx)))
+    opened = (np.abs(b) >= 1) | (np.abs(gg) <= 1)
+    assert ref_ok.sum() > n // 20 and (~ref_ok).sum() > n // 20
+    missed = ref_ok & ~opened
+    if with_slab:
+        assert not missed.any(), f"{int(missed.sum())} member accepts behind a closed group"
+        # and the cone is off for most cameras that are NOT near a member's plane (unless the
+        # triangles are so small for their distance that every accept is rounding noise)
+        if scale / size < 1000:
+            assert possible[~inplane & ~miss].mean() < 0.2
+    else:
+        assert missed.any()

@@ -368,6 +368,83 @@ def test_sphere_groups_vs_oracle(esc, renderer, case):
         assert ref.sum() > 0
 
 
+def _grid_mesh(nx, nz, x0, x1, z0, z1, height):
+    """(nx x nz quads) x 2 triangles over [x0,x1] x [z0,z1], y = height(x, z), facing +y; float64
+    vertices [n, 3, 3]"""
+    xs, zs = np.linspace(x0, x1, nx + 1), np.linspace(z0, z1, nz + 1)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    P = np.stack([X, height(X, Z), Z], axis=-1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    return np.concatenate([np.stack([a, c, b], axis=2).reshape(-1, 3, 3),   # normals up (+y)
+                           np.stack([a, d, c], axis=2).reshape(-1, 3, 3)])
+
+
+@pytest.mark.parametrize("case", ["camera in the plane of a tessellated floor",
+                                  "light flush with a tessellated ceiling",
+                                  "equal t: the same mesh twice", "slivers and collapsed triangles",
+                                  "a small mesh far away", "bumps seen at a grazing angle"])
+def test_triangle_groups_vs_oracle(esc, renderer, case):
+    """From 64 triangles up the brute-force kernels test a bounding sphere and a normal cone per
+    k-d ordered run of 8 / 64 triangles first (csrc/rt_device.h TriGroups).  Scenes against the
+    cone's "nearly parallel" escape and the ordering: rays and origins IN the plane of many
+    coplanar triangles (accepts there are rounding noise, and the groups must still let every
+    one of them through), hits at equal t on triangles of different geometries, slivers and
+    zero-area triangles inside groups, a far mesh of tiny triangles, silhouettes of a bumpy mesh.
+    Frame == oracle bit for bit, 1-3 lights; == index order == exact-only == queue form."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    eye, look = np.array([0.0, 1.0, 6.0]), np.array([0.0, 1.0, 0.0])
+    flat = lambda X, Z: np.zeros_like(X)
+    meshes = [(_grid_mesh(12, 12, -6, 6, -8, 4, flat), ol.WHITE)]
+    l1 = np.array([[-0.3, 7, -1], [0.3, 7, -1], [0, 7, -1.6]], float)
+    if case == "camera in the plane of a tessellated floor":
+        eye, look = np.array([0.3, 0.0, 3.7]), np.array([0.0, 0.0, -2.0])  # y == 0 exactly
+        meshes.append((_grid_mesh(6, 6, -2, 2, -4, -1, lambda X, Z: 0.5 + 0.3 * np.sin(X) * np.cos(Z)),
+                       ol.material13(ka=(0.3, 0.6, 0.8), kd=(0.3, 0.6, 0.8))))
+    elif case == "light flush with a tessellated ceiling":
+        meshes.append((_grid_mesh(10, 10, -6, 6, -8, 4, lambda X, Z: np.full_like(X, 7.0))[:, ::-1],
+                       ol.material13(ka=(0.7, 0.7, 0.6), kd=(0.7, 0.7, 0.6))))
+        eye, look = np.array([0.0, 0.5, 3.5]), np.array([0.0, 5.5, -2.0])  # looking up at it
+    elif case == "equal t: the same mesh twice":
+        bump = _grid_mesh(9, 9, -3, 3, -5, 1, lambda X, Z: 0.6 + 0.5 * np.sin(1.3 * X) * np.cos(0.9 * Z))
+        meshes.append((bump, ol.material13(ka=(0.8, 0.2, 0.2), kd=(0.8, 0.2, 0.2))))
+        meshes.append((bump[rng.permutation(len(bump))], ol.material13(ka=(0.2, 0.8, 0.2), kd=(0.2, 0.8, 0.2))))
+    elif case == "slivers and collapsed triangles":
+        m = _grid_mesh(10, 10, -3, 3, -5, 1, lambda X, Z: 0.8 + 0.4 * np.cos(X + Z))
+        m[::7, 2] = m[::7, 0] + (m[::7, 1] - m[::7, 0]) * 0.5      # collinear: zero area
+        m[3::11, 2] = m[3::11, 1]                                  # two equal vertices
+        m[5::13, 2] = m[5::13, 0] + (m[5::13, 1] - m[5::13, 0]) * 0.3 + 1e-6  # slivers
+        meshes.append((m, ol.material13(ka=(0.6, 0.5, 0.9), kd=(0.6, 0.5, 0.9))))
+    elif case == "a small mesh far away":
+        meshes.append((_grid_mesh(12, 12, -0.4, 0.4, -300.4, -299.6,
+                                  lambda X, Z: 40 + 0.2 * np.sin(9 * X) * np.cos(7 * Z)),
+                       ol.material13(ka=(0.9, 0.9, 0.2), kd=(0.9, 0.9, 0.2))))
+        look = np.array([0.0, 40.0 * 6 / 306 + 1.0, 0.0])
+    elif case == "bumps seen at a grazing angle":
+        eye, look = np.array([0.0, 0.9, 5.0]), np.array([0.0, 0.3, -3.0])
+        meshes.append((_grid_mesh(24, 24, -5, 5, -7, 3, lambda X, Z: 0.4 * np.sin(1.7 * X) * np.cos(1.3 * Z) + 0.41),
+                       ol.material13(ka=(0.4, 0.7, 0.5), kd=(0.4, 0.7, 0.5))))
+    l2 = np.array([[4, 5, 2], [4.4, 5, 2], [4, 5.4, 2.2]], float)
+    l3 = np.array([[-5, 3, 3], [-5, 3.3, 3], [-4.8, 3, 3.3]], float)
+    for lights in ([l1], [l1, l2], [l1, l2, l3]):
+        geoms = [{"vertex": m.reshape(-1, 3).astype(np.float32),
+                  "face_index": np.arange(3 * len(m)).reshape(-1, 3), "material": mat}
+                 for m, mat in meshes]
+        for lt in lights:
+            geoms.append({"vertex": lt.astype(np.float32), "face_index": np.array([[0, 1, 2]]),
+                          "material": ol.LIGHT_A})
+        d = ol.scene_dict(geoms, np.zeros((0, 4), np.float32), np.zeros((0, 13), np.float32))
+        W, H = 224, 128
+        for px in (1, 2):
+            gpu, u8, ref = render_both(esc, renderer, d, tuple(eye), tuple(look), W, H, px=px)
+            assert_bit_equal(gpu, ref, f"tri groups/{case}/{len(lights)} lights/px{px}")
+        cam = esc.Camera.for_image(tuple(eye), tuple(look), W, H)
+        for flags in (esc.ESC_RENDER_INDEX_ORDER, esc.ESC_RENDER_EXACT_ONLY,
+                      esc.ESC_RENDER_SHADE_QUEUE):
+            other = renderer.render(cam, W, H, flags=flags)
+            assert_bit_equal(other, ref, f"tri groups/{case}/{len(lights)} lights/flags{flags}")
+        assert ref.sum() > 0
+
+
 @pytest.mark.parametrize("form", ["queue", "fused"])
 def test_both_shading_forms_on_small_frames(esc, renderer, form):
     """The queue form is chosen by default only for long primitive lists on large bands; force
