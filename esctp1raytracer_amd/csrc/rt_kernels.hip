@@ -468,6 +468,18 @@ DEVINL f3 primary_dir(const RenderParams &p, int w, int h) {
   return normalize(((ld3(p.llc) + ld3(p.horizontal) * is) + ld3(p.vertical) * it) - origin);
 }
 
+// This thread's tile position, RECOMPUTED from the thread id through an opaque copy: used by
+// k_shade<SMEM> inside and after the light loop, so that pixel coordinates and tile fields do not
+// occupy VGPRs across the any-hit sweeps (they cost 36 B of scratch per lane there otherwise).
+DEVINL Tile<1> tile_again(const RenderParams &p) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int tiles_x = (p.W + 31) / 32;
+  Tile<1> T(p, blockIdx.x % tiles_x, blockIdx.x / tiles_x, t);
+  T.wave = __builtin_amdgcn_readfirstlane(T.wave);
+  return T;
+}
+
 template <int STAGE, typename V, int NV>
 __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   constexpr int PX = NV * lanes_of<V>::n; // pixels per work-item
@@ -570,8 +582,11 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
 
 // waves per SIMD asked of the register allocator: 6 (80 VGPRs) measured best for the SMEM and BVH
 // variants (5 and 4 were 1 % slower / no different); the LDS variant's 46 KB of LDS allow 4
-template <int STAGE>
-__global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (STAGE == STAGE_SMEM ? 5 : 6)) k_shade(const RenderParams p) {
+// TGRP: the scene has triangle groups (rt_device.h TriGroups).  Their sweep needs more registers
+// than 6 waves per SIMD leave (36 B of scratch per lane otherwise), so that variant is built for 5
+// and scenes without triangle groups keep the leaner kernel.
+template <int STAGE, bool TGRP = false>
+__global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) k_shade(const RenderParams p) {
   typedef float V;
   constexpr int NV = 1;
   constexpr int TW = 32;
@@ -666,18 +681,24 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (STAGE == STAGE_
     a[0].tocc = 0.f;
     a[0].kocc = -1;
     if (has_hit) {
+      int ww = w, hh = h;
+      if constexpr (STAGE == STAGE_SMEM) { // not kept live across the sweeps (tile_again)
+        const Tile<1> Ta = tile_again(p);
+        ww = Ta.w0 + Ta.lx0;
+        hh = Ta.h_tile + Ta.ly;
+      }
       // x % 1 == 0: a one-face light needs no draw (wave-uniform shortcut)
       const uint32_t face =
           (p.face_mode == 0) ? (uint32_t)p.fixed_face
           : (Lt.n_faces == 1) ? 0u
-                              : face_hash(p.seed, (uint32_t)(h * p.W + w), (uint32_t)li,
+                              : face_hash(p.seed, (uint32_t)(hh * p.W + ww), (uint32_t)li,
                                           (uint32_t)Lt.n_faces);
       const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
       lP = P;
       lpt = Lt.first_point + (int)face;
       // the primary direction is recomputed here (same ops, same bits) rather than kept in
       // registers across the any-hit loops of the previous light
-      const f3 dir = (STAGE == STAGE_BVH) ? dir_kept : primary_dir(p, w, h);
+      const f3 dir = (STAGE == STAGE_BVH) ? dir_kept : primary_dir(p, ww, hh);
       ro = origin + dir * (t - FLT_EPSILON); // :757-758
       rL = P - ro;                           // :759
       const float len = length(rL);          // :761
@@ -739,7 +760,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (STAGE == STAGE_
         const bool grp = (li == p.n_lights - 1) && p.use_filter && p.sg.n_grp > 0;
         const int n_rec = grp ? p.sg.n_grp * (kSphGroup / 2) : (p.n_sph + 1) >> 1;
         // ... and the triangle GROUPS (rt_device.h TriGroups): k0 counts sorted slots, 8 per group
-        const bool tgrp = (li == p.n_lights - 1) && p.use_filter && p.tg.n_grp > 0;
+        const bool tgrp = TGRP && (li == p.n_lights - 1) && p.use_filter && p.tg.n_grp > 0;
         const int n_tri_sweep = tgrp ? p.tg.n_grp * kTriGroup : p.n_tri;
         int k0 = 0, seg = tgrp ? kSegGroupPairs : kSegTris; // triangles first (index order)
         bool in_tris = p.n_tri > 0;
@@ -766,7 +787,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (STAGE == STAGE_
             aa[0].kocc = -1;
             const f3 so = mk(R.ox[rs], R.oy[rs], R.oz[rs]);
             const f3 sL = mk(R.lx[rs], R.ly[rs], R.lz[rs]);
-            if (in_tris && tgrp) {
+            if (TGRP && in_tris && tgrp) {
               bool far;
               const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
               const RayF rs = make_ray_filter(so, sL, p.shadow_center);
@@ -902,9 +923,19 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (STAGE == STAGE_
     }
   }
 
-  emit_counters(p, tid, lane, inside, has_hit, n_shadow, n_any, (unsigned long long)n_swept * 64ull,
-                true);
-  write_tile(p, T, tid, r, g, b, inside, lds_px);
+  if constexpr (STAGE == STAGE_SMEM) { // tile fields recomputed, not kept live (tile_again)
+    const Tile<1> Te = tile_again(p);
+    const int tid_e = Te.wave * 64 + Te.lane;
+    const bool inside_e = (Te.lr0 + Te.ly < p.n_local_rows) && (Te.h_tile + Te.ly < p.H) &&
+                          (Te.w0 + Te.lx0 < p.W);
+    emit_counters(p, tid_e, Te.lane, inside_e, has_hit, n_shadow, n_any,
+                  (unsigned long long)n_swept * 64ull, true);
+    write_tile(p, Te, tid_e, r, g, b, inside_e, lds_px);
+  } else {
+    emit_counters(p, tid, lane, inside, has_hit, n_shadow, n_any, (unsigned long long)n_swept * 64ull,
+                  true);
+    write_tile(p, T, tid, r, g, b, inside, lds_px);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1325,7 +1356,10 @@ extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, 
   } else {
     launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream); // always 2 px: see esc_launch_primary_only
     if (between) (void)hipEventRecord(between, stream);
-    hipLaunchKernelGGL((esc::k_shade<esc::STAGE_SMEM>), dim3(shade_grid), dim3(256), 0, stream, *p);
+    if (p->use_filter && p->tg.n_grp > 0)
+      hipLaunchKernelGGL((esc::k_shade<esc::STAGE_SMEM, true>), dim3(shade_grid), dim3(256), 0, stream, *p);
+    else
+      hipLaunchKernelGGL((esc::k_shade<esc::STAGE_SMEM>), dim3(shade_grid), dim3(256), 0, stream, *p);
   }
   return (int)hipGetLastError();
 }
