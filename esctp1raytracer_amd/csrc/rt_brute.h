@@ -805,11 +805,11 @@ DEVINL void test_tri2_primary_sorted(const DevTriP (&T)[2], int id0, int id1, co
 }
 
 // n_sup is a multiple of kTriGroupStep (= 4; pad records never open).  Super-group s holds groups
-// [8 s, 8 s + 8), group g the sorted slots [8 g, 8 g + 8).
+// [kTriSuper s, kTriSuper (s + 1)), group g the sorted slots [8 g, 8 g + 8).
 template <typename FetchP, typename FetchF, typename FetchE, typename FetchI>
 DEVINL void closest_tri_primary_groups(FetchP recu, FetchP recg, FetchP recp, FetchF recf, FetchE rece,
                                        FetchI reci, int n_sup, const V3<v2f> &d, Hit (&h)[2]) {
-  static_assert(kTriGroup == 8 && kTriSuper == 8 && kTriGroupStep == 4, "4-wide bodies below");
+  static_assert(kTriGroup == 8 && kTriSuper % 4 == 0 && kTriGroupStep == 4, "4-wide bodies below");
   auto level2 = [&](int k) { // sorted triangles k, k+1 (k even)
     const TriF T[2] = {recf(k), recf(k + 1)};
     v2f A[2], B[2], C[2];
@@ -858,16 +858,16 @@ DEVINL void closest_tri_primary_groups(FetchP recu, FetchP recg, FetchP recp, Fe
     }
     return mask;
   };
-  auto groups = [&](int s) { // the 8 groups of super-group s, 4 at a time
-    for (int half = 0; half < 2; ++half) {
+  auto groups = [&](int s) { // the kTriSuper groups of super-group s, 4 at a time
+    for (int q4 = 0; q4 < kTriSuper; q4 += 4) {
       TriPF G[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) G[i] = recg(8 * s + 4 * half + i);
+      for (int i = 0; i < 4; ++i) G[i] = recg(kTriSuper * s + q4 + i);
       uint32_t mask = open4(G);
       while (mask) {
         const int j = __builtin_ctz(mask);
         mask &= mask - 1;
-        const int g0 = 8 * (8 * s + 4 * half + j);
+        const int g0 = kTriGroup * (kTriSuper * s + q4 + j);
         members4(g0);
         members4(g0 + 4);
       }
@@ -1210,15 +1210,16 @@ DEVINL int anyhit_tri_groups_filter(FetchP recu, FetchP recg, FetchP recp, Fetch
     }
     return mask;
   };
-  auto groups = [&](int s) { // the 8 groups = 4 pair records of super-group s, 2 records at a time
-    for (int half = 0; half < 2; ++half) {
-      const TriPairPF G[2] = {recg(4 * s + 2 * half), recg(4 * s + 2 * half + 1)};
+  auto groups = [&](int s) { // the kTriSuper groups of super-group s, 2 pair records (4 groups) at a time
+    for (int q4 = 0; q4 < kTriSuper; q4 += 4) {
+      const int r = (kTriSuper * s + q4) >> 1;
+      const TriPairPF G[2] = {recg(r), recg(r + 1)};
       uint32_t mask = open_mask(G);
       swept += 4;
       while (mask) {
         const int j = __builtin_ctz(mask);
         mask &= mask - 1;
-        members(8 * s + 4 * half + j);
+        members(kTriSuper * s + q4 + j);
         swept += kTriGroup;
       }
     }

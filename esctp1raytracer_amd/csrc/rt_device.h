@@ -194,7 +194,7 @@ struct DevLight {
 // parallel to ANY member has |d . a| <= kappa.  Static part per group:
 // ---------------------------------------------------------------------------------------
 constexpr int kTriGroup = 8;
-constexpr int kTriSuper = 8;
+constexpr int kTriSuper = 16;
 constexpr int kTriGroupStep = 4; // super-groups per sweep step: n_sup is a multiple of this
 constexpr int kTriGroupMinTris = 64;
 struct alignas(16) DevTriGroup {

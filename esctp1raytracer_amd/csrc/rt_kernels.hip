@@ -203,10 +203,25 @@ __global__ void __launch_bounds__(256) k_prepare_groups(const SphGroups g, float
 // (P) of rt_brute.h "Triangle GROUPS": may a ray from the camera o be accepted by triangle T through
 // the pre-filter's "nearly parallel" escape at all?  Only if the camera lies within H of T's plane.
 // Everything in fp32 from T's own record; 1 % + 16u |tvec| on top of H cover the roundings, and
-// every doubtful case (a sliver, a non-finite value) answers yes.
-DEVINL bool tri_escape_possible(const DevTri &T, f3 o) {
+// every doubtful case (a sliver, a non-finite value) answers yes with no usable normal.
+struct TriEscape {
+  bool possible; // the camera is within H of the plane (or nothing can be said)
+  bool bounded;  // nh / beta below are valid: the escape needs |d . nh| < beta
+  f3 nh;         // unit normal
+  float beta;    // tau / |n1| for this camera
+};
+DEVINL TriEscape tri_escape(const DevTri &T, f3 o) {
+  TriEscape E;
+  E.possible = true;
+  E.bounded = false;
+  E.nh = mk(0.f, 0.f, 0.f);
+  E.beta = 0.f;
   const float u = 0x1p-24f;
   const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+  if (e1.x == 0.f && e1.y == 0.f && e1.z == 0.f && e2.x == 0.f && e2.y == 0.f && e2.z == 0.f) {
+    E.possible = false; // pad slot (or a point): det == 0 exactly, rejected
+    return E;
+  }
   const f3 tv = o - ld3(T.v0);
   const f3 n1 = cross(e2, e1);
   const float nn = sqrtf(dot(n1, n1));
@@ -217,16 +232,20 @@ DEVINL bool tri_escape_possible(const DevTri &T, f3 o) {
   const f3 s3 = (e1 + e2) * (1.f / 3.f);
   const float rho = sqrtf(fmaxf(fmaxf(dot(s3, s3), dot(e1 - s3, e1 - s3)), dot(e2 - s3, e2 - s3)));
   const float emax = fmaxf(l1, l2);
-  if (!(rho > 0x1.2p-10f * emax) || !(nn > 0.f)) return true; // sliver / no normal
+  if (!(rho > 0x1.2p-10f * emax) || !(nn > 0.f)) return E; // sliver / no normal
   const float p12 = a1 * a2;
   const float k = 3.2f * u * emax / rho * 1.0001f;
   const float tau = k * ((10.04f * a2 + 5.04f * a1) * at + 20.1f * p12);
-  if (!(tau < 0.1f * nn)) return true; // |d . n| < 0.1 is part of the argument
+  if (!(tau < 0.1f * nn)) return E; // |d . n| < 0.1 is part of the argument
   const float ted = (tau + 10.05f * u * p12) * (1.f + 4.f * u);
   const float U = ted + 10.04f * u * at * a2, V = ted + 5.04f * u * at * a1;
   const float H = (fmaxf(V / l1, U / l2) + at * tau / nn) * (2.f * l1 * l2 / nn) * (1.f / 0.99f);
   const float h = fabsf(dot(tv, n1)) / nn;
-  return !(h > H * 1.01f + 0x1p-20f * at); // NaN: yes
+  E.possible = !(h > H * 1.01f + 0x1p-20f * at); // NaN: yes
+  E.nh = n1 * (1.f / nn);
+  E.beta = tau / nn;
+  E.bounded = (E.nh.x == E.nh.x) && (E.nh.y == E.nh.y) && (E.nh.z == E.nh.z) && (E.beta == E.beta);
+  return E;
 }
 
 // per-frame records of the triangle groups (rt_device.h TriGroups): the sorted triangles' forms,
@@ -252,30 +271,55 @@ __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, f
         const float R = (G.rgeo + 0x1p-21f * at) + 0x1p-60f;
         const float R2 = R * R * 1.00001f;
         const DevSphF F = sphere_filter_record(oc, dot(oc, oc) - R2, R2);
-        const float kappa = (((G.smax + G.b0) + G.b1 * at) + 0x1p-20f) * 1.0001f;
         Q.sx = F.sx;
         Q.sy = F.sy;
         Q.sz = F.sz;
         Q.w = F.w;
-        // (P): no member can be accepted through the escape unless the camera is within H_t of
-        // its plane -- checked member by member (8 or 64 of them) for this frame's camera
+        // (P): only members whose plane the camera is within H_t of can be accepted through the
+        // escape, and only by rays with |d . n_t| < beta_t.  The cone of THIS frame is therefore
+        // built over those members alone (8 or kTriGroup kTriSuper candidates; mostly none):
+        // axis a = mean of their unit normals, |d . a| <= beta_t + |d| |a x n_t| for each of them.
         const int per = (i < g.n_grp) ? kTriGroup : kTriGroup * kTriSuper;
         const int first = ((i < g.n_grp) ? i : (i - g.n_grp)) * per;
-        bool possible = false;
-        for (int m = 0; m < per && !possible; ++m) {
-          const DevTri T = g.sorted[first + m];
-          const bool pad_slot = T.e1[0] == 0.f && T.e1[1] == 0.f && T.e1[2] == 0.f && T.e2[0] == 0.f &&
-                                T.e2[1] == 0.f && T.e2[2] == 0.f; // det == 0 exactly: rejected
-          possible = !pad_slot && tri_escape_possible(T, o);
+        f3 acc = mk(0.f, 0.f, 0.f), ref = mk(0.f, 0.f, 0.f);
+        float bmax = 0.f;
+        int cnt = 0;
+        bool unbounded = false;
+        for (int m = 0; m < per; ++m) {
+          const TriEscape E = tri_escape(g.sorted[first + m], o);
+          if (!E.possible) continue;
+          if (!E.bounded) {
+            unbounded = true;
+            break;
+          }
+          if (cnt == 0) ref = E.nh;
+          acc = acc + E.nh * ((dot(E.nh, ref) < 0.f) ? -1.f : 1.f);
+          bmax = fmaxf(bmax, E.beta);
+          ++cnt;
         }
-        const bool no_escape = !possible;
-        if (no_escape) {
-          Q.gx = 0x1p60f; // |g''| <= 1 only for |d.x| <= 2^-60: a needless opening at worst
-        } else if (kappa < 1.f) { // else g'' = 0: always "nearly parallel"
-          const float ik = 1.f / kappa;
-          Q.gx = G.ax * ik;
-          Q.gy = G.ay * ik;
-          Q.gz = G.az * ik;
+        const float an = sqrtf(dot(acc, acc));
+        if (!unbounded && cnt > 0 && !(an > 0.5f * (float)cnt)) unbounded = true; // no useful axis
+        if (unbounded) {
+          // g'' = 0: always "nearly parallel" (Q.g* are 0)
+        } else if (cnt == 0) {
+          Q.gx = 0x1p60f; // no ray of this frame can take the escape here
+        } else {
+          const f3 ax = acc * (1.f / an);
+          float smax = 0.f;
+          for (int m = 0; m < per; ++m) {
+            const TriEscape E = tri_escape(g.sorted[first + m], o);
+            if (!E.possible) continue;
+            const f3 c = cross(ax, E.nh);
+            smax = fmaxf(smax, sqrtf(dot(c, c)));
+          }
+          // 1e-5: the fp32 normals and axis; 2^-20: the FMA chain of g'' and |d| - 1
+          const float kp = (((smax + 1e-5f) * 1.0001f + bmax) + 0x1p-20f) * 1.0001f;
+          if (kp < 1.f) {
+            const float ik = 1.f / kp;
+            Q.gx = ax.x * ik;
+            Q.gy = ax.y * ik;
+            Q.gz = ax.z * ik;
+          }
         }
       }
     }
@@ -792,14 +836,15 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
               const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
               const RayF rs = make_ray_filter(so, sL, p.shadow_center);
               int n_open = 0;
-              // k0 sorted slots in = k0 / 8 groups = k0 / 64 super-groups; two per pair record
+              // k0 sorted slots in = k0 / 8 groups = k0 / (8 kTriSuper) super-groups; two per pair record
               n_swept += anyhit_tri_groups_filter(
                   SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) +
-                                       (p.tg.n_grp >> 1) + (k0 >> 7)},
+                                       (p.tg.n_grp >> 1) + k0 / (2 * kTriGroup * kTriSuper)},
                   SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) + (k0 >> 4)},
                   SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.sorted2_pf) + (k0 >> 1)},
                   SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tg.sorted2_f) + (k0 >> 1)},
-                  SmemFetch<DevTri>{p.tg.sorted + k0}, n_here >> 6, k0, so, sL, rs, rt, far, aa,
+                  SmemFetch<DevTri>{p.tg.sorted + k0}, n_here / (kTriGroup * kTriSuper), k0, so, sL, rs,
+                  rt, far, aa,
                   n_open);
               if (rr >= 0 && n_open) R.n_open[rr] += n_open;
             } else if (in_tris) {
@@ -893,7 +938,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
           // had opened.
           const int k = a[0].kocc;
           const bool by_tri = k >= 0 && k < p.n_tri;
-          unsigned cnt = tri_groups ? (unsigned)(by_tri ? (k >> 6) + 1 : p.tg.n_sup)
+          unsigned cnt = tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper) + 1 : p.tg.n_sup)
                                     : (unsigned)(by_tri ? k + 1 : p.n_tri);
           if (!by_tri)
             cnt += sph_groups ? (unsigned)(k >= 0 ? ((k - p.n_tri) >> 6) + 1 : p.sg.n_sup)

@@ -619,7 +619,8 @@ def test_triangle_shadow_prefilter_never_rejects_a_reference_candidate(scale, si
 
 # ------------------------------------------------------------------ triangle groups
 def _escape_possible(o, v0, e1, e2):
-    """numpy mirror of k_prepare_tri_groups' tri_escape_possible (fp32), one camera per row"""
+    """numpy mirror of k_prepare_tri_groups' tri_escape (fp32), one camera per row: possible,
+    bounded (unit normal and beta are usable), unit normal, beta = tau / |n1|"""
     u = f32(2.0 ** -24)
     tv = [f32(o[:, i] - v0[:, i]) for i in range(3)]
     n1 = ref_cross(e2[:, 0], e2[:, 1], e2[:, 2], e1[:, 0], e1[:, 1], e1[:, 2])
@@ -647,16 +648,20 @@ def _escape_possible(o, v0, e1, e2):
         H = f32(f32(f32(np.maximum(f32(V / len1), f32(U / len2)) + f32(f32(at * tau) / nn)) *
                     f32(f32(f32(f32(2) * len1) * len2) / nn)) * f32(f32(1) / f32(0.99)))
         h = f32(np.abs(d3(tv, n1)) / nn)
+        bounded = ~yes
         yes |= ~(h > f32(f32(H * f32(1.01)) + f32(f32(2.0 ** -20) * at)))
-    return yes
+        inv = f32(f32(1) / nn)
+        nh = np.stack([f32(n1[0] * inv), f32(n1[1] * inv), f32(n1[2] * inv)], axis=1)
+        beta = f32(tau / nn)
+    return yes, bounded, nh, beta
 
 
 @pytest.mark.parametrize("scale,size,with_slab", [(1.0, 0.3, True), (30.0, 0.1, True), (30.0, 3.0, True),
                                                   (1000.0, 0.05, True), (30.0, 3.0, False)])
 def test_triangle_primary_group_never_rejects_a_member_candidate(scale, size, with_slab):
     """rt_device.h TriGroups, primary rays: the group record (bounding sphere of the members'
-    pre-filter spheres OR "nearly parallel to the cone of their normals", the cone part switched
-    off when the camera is in no member's slab -- statement (P) of rt_brute.h) against the
+    pre-filter spheres OR "nearly parallel" to the frame's cone -- built over the members whose
+    plane the camera is within H_t of, statement (P) of rt_brute.h; none: no cone) against the
     reference accept of a member.  Groups of 8 triangles off a bumpy patch; cameras anywhere and
     (half of them) a hair off a member's plane, rays that hug the member's edges or run nearly in
     its plane.  Static bounds come from the library (esc_tri_group_record, host only); the
@@ -736,16 +741,44 @@ def test_triangle_primary_group_never_rejects_a_member_candidate(scale, size, wi
     R = f32(f32(G[:, 3] + f32(f32(2.0 ** -21) * at)) + f32(2.0 ** -60))
     R2 = f32(f32(R * R) * f32(1.00001))
     sx, sy, sz, w = _scaled_record(oc[0], oc[1], oc[2], f32(ref_dot(*oc, *oc) - R2), R2)
-    kappa = f32(f32(f32(f32(G[:, 7] + G[:, 9]) + f32(G[:, 10] * at)) + f32(2.0 ** -20)) * f32(1.0001))
-    possible = np.zeros(n, bool)
-    if with_slab:
+    # the frame's cone: over the members whose plane the camera is within H_t of, only
+    acc = np.zeros((n, 3), f32)
+    ref = np.zeros((n, 3), f32)
+    bmax = np.zeros(n, f32)
+    cnt = np.zeros(n, np.int32)
+    unbounded = np.zeros(n, bool)
+    flagged, normals = [], []
+    for m in range(8):
+        pos, bnd, nh, beta = _escape_possible(o, V0[gi, m], E1[gi, m], E2[gi, m])
+        if not with_slab:
+            pos = np.zeros(n, bool)
+        unbounded |= pos & ~bnd
+        use = pos & bnd
+        first = use & (cnt == 0)
+        ref = np.where(first[:, None], nh, ref)
+        sgn = np.where(ref_dot(nh[:, 0], nh[:, 1], nh[:, 2], ref[:, 0], ref[:, 1], ref[:, 2]) < 0, f32(-1), f32(1))
+        acc = np.where(use[:, None], f32(acc + f32(nh * sgn[:, None])), acc)
+        bmax = np.where(use, np.maximum(bmax, beta), bmax)
+        cnt += use
+        flagged.append(use)
+        normals.append(nh)
+    possible = unbounded | (cnt > 0)
+    with np.errstate(all="ignore"):
+        an = np.sqrt(ref_dot(acc[:, 0], acc[:, 1], acc[:, 2], acc[:, 0], acc[:, 1], acc[:, 2]), dtype=f32)
+        unbounded |= (cnt > 0) & ~(an > f32(0.5) * cnt.astype(f32))
+        ax = f32(acc * f32(f32(1) / an)[:, None])
+        smax = np.zeros(n, f32)
         for m in range(8):
-            possible |= _escape_possible(o, V0[gi, m], E1[gi, m], E2[gi, m])
-    cone = possible & (kappa < 1)
-    ik = f32(f32(1) / kappa)
-    gxv = np.where(cone, f32(G[:, 4] * ik), np.where(possible, f32(0), f32(2.0 ** 60)))
-    gyv = np.where(cone, f32(G[:, 5] * ik), f32(0))
-    gzv = np.where(cone, f32(G[:, 6] * ik), f32(0))
+            c = ref_cross(ax[:, 0], ax[:, 1], ax[:, 2], normals[m][:, 0], normals[m][:, 1], normals[m][:, 2])
+            sm = np.sqrt(ref_dot(c[0], c[1], c[2], c[0], c[1], c[2]), dtype=f32)
+            smax = np.where(flagged[m], np.maximum(smax, sm), smax)
+        kp = f32(f32(f32(f32(f32(smax + f32(1e-5)) * f32(1.0001)) + bmax) + f32(2.0 ** -20)) * f32(1.0001))
+        cone = ~unbounded & (cnt > 0) & (kp < 1)
+        ik = f32(f32(1) / kp)
+    never = ~unbounded & (cnt == 0)
+    gxv = np.where(cone, f32(ax[:, 0] * ik), np.where(never, f32(2.0 ** 60), f32(0)))
+    gyv = np.where(cone, f32(ax[:, 1] * ik), f32(0))
+    gzv = np.where(cone, f32(ax[:, 2] * ik), f32(0))
     b = fma(sz, dz, fma(sy, dy, fma(sx, dx, w)))
     gg = fma(gzv, dz, fma(gyv, dy, f32(gxv * dx)))
     opened = (np.abs(b) >= 1) | (np.abs(gg) <= 1)
