@@ -538,11 +538,16 @@ def main():
                     cyc = (nf * CYC_PK_FMA + npk * CYC_PK + npl * CYC_PLAIN) / (nf + npk + npl)
                     clock_ghz = prof.get("clock_ghz", 2.4)
                     avail = ent["ms"] * 1e-3 * clock_ghz * 1e9 * 1024  # SIMD-cycles
-                    ent.update({"valu_insts": insts, "loop_mix_pkfma_pk_plain": [nf, npk, npl],
-                                "cycles_per_inst_at_full_issue": cyc, "clock_ghz": clock_ghz,
-                                "issue_frac": insts * cyc / avail,
-                                "lane_ops_per_s": insts * 64 * (1 + (nf + npk) / (nf + npk + npl))
-                                / (ent["ms"] * 1e-3)})
+                    # executed VALU instructions per SIMD-cycle against what the pipe can issue:
+                    # between 1 / 5.04 (nothing but v_pk_fma_f32) and 1 / 2.66 (nothing but plain
+                    # VALU); `issue_frac` prices every instruction at the filter bodies' mix and
+                    # can exceed 1 where the sweeps' bookkeeping (cheaper plain VALU) dominates
+                    ent.update({"valu_insts": insts, "clock_ghz": clock_ghz,
+                                "valu_insts_per_simd_cycle": insts / avail,
+                                "issue_ceiling_per_simd_cycle": [1 / CYC_PK_FMA, 1 / CYC_PLAIN],
+                                "filter_body_mix_pkfma_pk_plain": [nf, npk, npl],
+                                "cycles_per_inst_at_body_mix": cyc,
+                                "issue_frac": insts * cyc / avail})
                 ks[name] = ent
             out["kernels"] = ks
         if pipelined is not None:

@@ -225,18 +225,24 @@ enum {
    * (k_primary, k_shade); esc_last_kernel_ms reads them.  Brute-force stages only: under
    * ESC_STAGE_BVH the frame is one kernel and ms[0] is 0. */
   ESC_RENDER_TIME_KERNELS = 2,
-  /* occlusion() (main.cpp:314-329) tests primitives in index order and returns at the first hit.
-   * For every light but the last that order is observable (the occluder's t2 moves the next
-   * light's shadow ray, quirk S3) and is kept.  For the LAST light only hit / no hit reaches the
-   * image, so long sphere lists are swept in order of decreasing solid angle seen from the light:
-   * occluded rays stop sooner, unoccluded rays still test every primitive -- same image, fewer
-   * tests.  esc_counters.anyhit_tests then counts the tests THIS order executed.  This flag keeps
-   * index order for the last light too (anyhit_tests == the reference's count). */
+  /* The reference tests primitives in index order: closest hit with a strict `t2 < *t` (the lower
+   * index keeps an equal t, main.cpp:176-192), occlusion() returning at the first hit
+   * (main.cpp:314-329).  By default the brute-force kernels test in ANOTHER order wherever that
+   * cannot be observed: from 64 spheres / 64 triangles up they sweep bounding spheres (and normal
+   * cones) of spatial groups of 8 and open only the groups a ray of the wavefront may touch
+   * (csrc/rt_device.h SphGroups / TriGroups) -- closest hits with the tie rule restated on the
+   * original index, shadow rays for the LAST light only (for the others the first occluder's t2
+   * moves the next light's ray, quirk S3, and index order is kept); shorter sphere lists of the
+   * last light are swept by decreasing solid angle.  Same image bit for bit, far fewer tests;
+   * esc_counters.anyhit_tests then counts what THIS order executed.  This flag switches all of
+   * that off: index order everywhere, anyhit_tests == the reference's count. */
   ESC_RENDER_INDEX_ORDER = 4,
   /* The shading pass has two forms with the same arithmetic: fused (one kernel, rays re-packed
    * inside each workgroup) and queue (one launch per segment of the primitive list, rays compacted
    * across the whole band).  By default the queue form is used for long lists (>= 2,048
-   * primitives) on large bands (>= 1.5 M pixels), where it is faster.  These force one. */
+   * primitives) on large bands (>= 1.5 M pixels) when the lists are swept linearly -- several
+   * lights, or ESC_RENDER_INDEX_ORDER; a single light's grouped lists always take the fused form,
+   * the only one that sweeps groups.  These force one. */
   ESC_RENDER_SHADE_QUEUE = 8,
   ESC_RENDER_SHADE_FUSED = 16
 };
@@ -248,8 +254,10 @@ typedef struct {
   uint64_t anyhit_tests; /* primitive tests those calls execute: up to and including the first
                             occluder met, else every primitive.  Equal to the reference's count
                             whenever the sweep is in index order (always with
-                            ESC_RENDER_INDEX_ORDER; see there).  Under ESC_STAGE_BVH: the tests
-                            the tree walk left for still-undecided rays */
+                            ESC_RENDER_INDEX_ORDER; see there).  Group sweeps: per ray, the
+                            super-group tests up to its occluder's (or all) plus 8 per group or
+                            super-group opened on its behalf.  Under ESC_STAGE_BVH: the tests the
+                            tree walk left for still-undecided rays */
   uint64_t anyhit_lane_tests; /* any-hit tests the GPU actually spent lanes on (64 per wave per
                                  primitive swept, decided or idle lanes included); the ratio
                                  anyhit_tests / anyhit_lane_tests is the lane efficiency of the

@@ -57,7 +57,7 @@ if "--current" in sys.argv:
 
     def frame_kernels(name):  # brute-force frame kernels only (the BVH leg has its own)
         return ("k_primary" in name or "k_shadow_setup" in name or "k_anyhit_segment" in name or
-                "k_shade_finish" in name or "k_shade<1>" in name or "k_shade<2>" in name)
+                "k_shade_finish" in name or "k_shade<1" in name or "k_shade<2" in name)
 
     prim = [k for k in out if "k_primary" in k]
     n_frames = {c: out[prim[0]][c]["launches"] for c in out[prim[0]] if c != "_dispatch"} if prim else {}
