@@ -498,15 +498,18 @@ DEVINL uint32_t sph8_primary_mask(const SphF2 (&S)[8], const V3<v2f> &d) {
   return mask;
 }
 
-// Two-level sweep (rt_device.h SphGroups): 8 super-groups per step, double-buffered; an opened
-// super-group costs one step over its 8 groups, an opened group one over its 8 spheres' filter
-// records, and only spheres that pass that run the reference arithmetic.  Super-group s holds
-// groups [8 s, 8 s + 8), group g the sorted slots [8 g, 8 g + 8); n_sup is a multiple of 8 (pad
-// records never pass).
+// Three-level sweep (rt_device.h SphGroups): 8 hyper-groups per step, double-buffered; an opened
+// hyper-group costs one step over its 8 super-groups, an opened super-group one over its 8 groups,
+// an opened group one over its 8 spheres' filter records, and only spheres that pass that run the
+// reference arithmetic.  Hyper-group y holds super-groups [8 y, 8 y + 8), super-group s groups
+// [8 s, 8 s + 8), group g the sorted slots [8 g, 8 g + 8); n_hyp is a multiple of 8 (pad records
+// never pass).
 template <typename FetchF, typename FetchE, typename FetchI>
-DEVINL void closest_sph_primary_groups(FetchF recu, FetchF recg, FetchF recf, FetchE rece, FetchI reci,
-                                       int n_sup, int base, const V3<v2f> &d, Hit (&h)[2]) {
-  static_assert(kSphGroup == 8 && kSphSuper == 8 && kSphGroupStep == 8, "8-wide bodies below");
+DEVINL void closest_sph_primary_groups(FetchF recy, FetchF recu, FetchF recg, FetchF recf, FetchE rece,
+                                       FetchI reci, int n_hyp, int base, const V3<v2f> &d,
+                                       Hit (&h)[2]) {
+  static_assert(kSphGroup == 8 && kSphSuper == 8 && kSphHyper == 8 && kSphGroupStep == 8,
+                "8-wide bodies below");
   auto members = [&](int g) {
     SphF2 S[8];
 #pragma unroll
@@ -532,22 +535,33 @@ DEVINL void closest_sph_primary_groups(FetchF recu, FetchF recg, FetchF recf, Fe
       members(8 * s + j);
     }
   };
-  auto step = [&](const SphF2(&U)[8], int s0) {
+  auto supers = [&](int y) { // the 8 super-groups of hyper-group y
+    SphF2 U[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) U[i] = recu(8 * y + i);
     uint32_t mask = sph8_primary_mask(U, d);
     while (mask) {
       const int j = __builtin_ctz(mask);
       mask &= mask - 1;
-      groups(s0 + j);
+      groups(8 * y + j);
+    }
+  };
+  auto step = [&](const SphF2(&Y)[8], int y0) {
+    uint32_t mask = sph8_primary_mask(Y, d);
+    while (mask) {
+      const int j = __builtin_ctz(mask);
+      mask &= mask - 1;
+      supers(y0 + j);
     }
   };
   SphF2 A[8], B[8];
-  fetch_batch(recu, 0, A);
-  for (int s = 0; s < n_sup; s += 16) {
-    fetch_batch(recu, recu.landed(A[7].yz, min(s + 8, n_sup - 8)), B);
-    step(A, s);
-    if (s + 8 >= n_sup) break; // odd number of steps: B was a clamped refetch, unused
-    fetch_batch(recu, recu.landed(B[7].yz, min(s + 16, n_sup - 8)), A);
-    step(B, s + 8);
+  fetch_batch(recy, 0, A);
+  for (int y = 0; y < n_hyp; y += 16) {
+    fetch_batch(recy, recy.landed(A[7].yz, min(y + 8, n_hyp - 8)), B);
+    step(A, y);
+    if (y + 8 >= n_hyp) break; // odd number of steps: B was a clamped refetch, unused
+    fetch_batch(recy, recy.landed(B[7].yz, min(y + 16, n_hyp - 8)), A);
+    step(B, y + 8);
   }
 }
 
@@ -804,12 +818,15 @@ DEVINL void test_tri2_primary_sorted(const DevTriP (&T)[2], int id0, int id1, co
   }
 }
 
-// n_sup is a multiple of kTriGroupStep (= 4; pad records never open).  Super-group s holds groups
-// [kTriSuper s, kTriSuper (s + 1)), group g the sorted slots [8 g, 8 g + 8).
+// n_hyp is a multiple of kTriGroupStep (= 4; pad records never open).  Hyper-group y holds
+// super-groups [kTriHyper y, kTriHyper (y + 1)), super-group s groups [kTriSuper s, kTriSuper (s + 1)),
+// group g the sorted slots [8 g, 8 g + 8).
 template <typename FetchP, typename FetchF, typename FetchE, typename FetchI>
-DEVINL void closest_tri_primary_groups(FetchP recu, FetchP recg, FetchP recp, FetchF recf, FetchE rece,
-                                       FetchI reci, int n_sup, const V3<v2f> &d, Hit (&h)[2]) {
-  static_assert(kTriGroup == 8 && kTriSuper % 4 == 0 && kTriGroupStep == 4, "4-wide bodies below");
+DEVINL void closest_tri_primary_groups(FetchP recy, FetchP recu, FetchP recg, FetchP recp, FetchF recf,
+                                       FetchE rece, FetchI reci, int n_hyp, const V3<v2f> &d,
+                                       Hit (&h)[2]) {
+  static_assert(kTriGroup == 8 && kTriSuper % 4 == 0 && kTriHyper % 4 == 0 && kTriGroupStep == 4,
+                "4-wide bodies below");
   auto level2 = [&](int k) { // sorted triangles k, k+1 (k even)
     const TriF T[2] = {recf(k), recf(k + 1)};
     v2f A[2], B[2], C[2];
@@ -873,22 +890,35 @@ DEVINL void closest_tri_primary_groups(FetchP recu, FetchP recg, FetchP recp, Fe
       }
     }
   };
-  auto step = [&](const TriPF(&U)[4], int s0) {
-    uint32_t mask = open4(U);
+  auto supers = [&](int y) { // the kTriHyper super-groups of hyper-group y, 4 at a time
+    for (int q4 = 0; q4 < kTriHyper; q4 += 4) {
+      TriPF U[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) U[i] = recu(kTriHyper * y + q4 + i);
+      uint32_t mask = open4(U);
+      while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        groups(kTriHyper * y + q4 + j);
+      }
+    }
+  };
+  auto step = [&](const TriPF(&Y)[4], int y0) {
+    uint32_t mask = open4(Y);
     while (mask) {
       const int j = __builtin_ctz(mask);
       mask &= mask - 1;
-      groups(s0 + j);
+      supers(y0 + j);
     }
   };
   TriPF A[4], B[4];
-  fetch_batch(recu, 0, A);
-  for (int s = 0; s < n_sup; s += 8) {
-    fetch_batch(recu, recu.landed(A[3].gz, min(s + 4, n_sup - 4)), B);
-    step(A, s);
-    if (s + 4 >= n_sup) break;
-    fetch_batch(recu, recu.landed(B[3].gz, min(s + 8, n_sup - 4)), A);
-    step(B, s + 4);
+  fetch_batch(recy, 0, A);
+  for (int y = 0; y < n_hyp; y += 8) {
+    fetch_batch(recy, recy.landed(A[3].gz, min(y + 4, n_hyp - 4)), B);
+    step(A, y);
+    if (y + 4 >= n_hyp) break;
+    fetch_batch(recy, recy.landed(B[3].gz, min(y + 8, n_hyp - 4)), A);
+    step(B, y + 4);
   }
 }
 
@@ -1172,15 +1202,16 @@ DEVINL void anyhit_tri_filter(FetchP recp, FetchF recf, FetchE rece, int n, int 
 // pre-filter's pair records: the bounding sphere in q' form with R = rgeo + 8u at, the cone axis
 // over kappa' = (smax + b0 + b1 at + 2^-20) * 1.0001, at = rho_max + |C - g|_1 + rext >= |O - v0_t|_1
 // for every member and every ray that starts within rho_max of g (host, rt_capi.cpp commit());
-// rays from further out (`far`) open everything.  4 super-groups per step; an opened super-group
-// costs two steps over its 8 groups, an opened group runs anyhit_tri_filter over its 8 triangles.
+// rays from further out (`far`) open everything.  4 hyper-groups per step; an opened hyper-group
+// costs two steps over its 8 super-groups, an opened super-group four over its 16 groups, an
+// opened group runs anyhit_tri_filter over its 8 triangles.
 // Returns the filter tests this wave swept (4 per step at any level); n_open counts the 8-record
 // openings each ray itself needed.
-constexpr int kTriGroupExitSteps = 4; // exit check every 16 super-groups
+constexpr int kTriGroupExitSteps = 4; // exit check every 16 hyper-groups
 template <typename FetchP, typename FetchF, typename FetchE>
-DEVINL int anyhit_tri_groups_filter(FetchP recu, FetchP recg, FetchP recp, FetchF recf, FetchE rece,
-                                    int n_sup, int base, f3 o, f3 L, const RayF &rs, const RayTF &rf,
-                                    bool far, Any (&a)[1], int &n_open) {
+DEVINL int anyhit_tri_groups_filter(FetchP recy, FetchP recu, FetchP recg, FetchP recp, FetchF recf,
+                                    FetchE rece, int n_hyp, int base, f3 o, f3 L, const RayF &rs,
+                                    const RayTF &rf, bool far, Any (&a)[1], int &n_open) {
   int swept = 0;
   auto members = [&](int g) { // sorted triangles [8 g, 8 g + 8) = pair records [4 g, 4 g + 4)
     anyhit_tri_filter(FetchP{recp.p + 4 * g}, FetchF{recf.p + 4 * g}, FetchE{rece.p + 8 * g}, kTriGroup,
@@ -1224,18 +1255,31 @@ DEVINL int anyhit_tri_groups_filter(FetchP recu, FetchP recg, FetchP recp, Fetch
       }
     }
   };
-  for (int s0 = 0; s0 < n_sup; s0 += 4 * kTriGroupExitSteps) {
-    if (!__builtin_amdgcn_ballot_w64(a[0].tb > 0.f)) return swept;
-    const int m = min(4 * kTriGroupExitSteps, n_sup - s0); // multiple of 4
-    swept += m;
-    // one register set, as in anyhit_tri_filter: the slow paths behind it leave no room for two
-    for (int s = 0; s < m; s += 4) {
-      const TriPairPF U[2] = {recu((s0 + s) >> 1), recu(((s0 + s) >> 1) + 1)};
+  auto supers = [&](int y) { // the kTriHyper super-groups of hyper-group y, 2 pair records at a time
+    for (int q4 = 0; q4 < kTriHyper; q4 += 4) {
+      const int r = (kTriHyper * y + q4) >> 1;
+      const TriPairPF U[2] = {recu(r), recu(r + 1)};
       uint32_t mask = open_mask(U);
+      swept += 4;
       while (mask) {
         const int j = __builtin_ctz(mask);
         mask &= mask - 1;
-        groups(s0 + s + j);
+        groups(kTriHyper * y + q4 + j);
+      }
+    }
+  };
+  for (int y0 = 0; y0 < n_hyp; y0 += 4 * kTriGroupExitSteps) {
+    if (!__builtin_amdgcn_ballot_w64(a[0].tb > 0.f)) return swept;
+    const int m = min(4 * kTriGroupExitSteps, n_hyp - y0); // multiple of 4
+    swept += m;
+    // one register set, as in anyhit_tri_filter: the slow paths behind it leave no room for two
+    for (int y = 0; y < m; y += 4) {
+      const TriPairPF Y[2] = {recy((y0 + y) >> 1), recy(((y0 + y) >> 1) + 1)};
+      uint32_t mask = open_mask(Y);
+      while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        supers(y0 + y + j);
       }
     }
   }
@@ -1515,15 +1559,16 @@ DEVINL int anyhit_sph_pairs_filter(FetchF recf, FetchE rece, int n_rec, int base
 // 8u R^2 instead of u r^2 is covered by km's 255u R^2), so km built from (C, R^2) by the same formula
 // makes q'_G >= 0.  Rays that start further than rho_max from g (quirk S3 can do that) treat every
 // group as a candidate.
-// Two levels, as for primary rays: 8 super-groups per step, an opened super-group costs one step
-// over its 8 groups, an opened group one over its 8 spheres.
+// Three levels, as for primary rays: 8 hyper-groups per step, an opened hyper-group costs one step
+// over its 8 super-groups, an opened super-group one over its 8 groups, an opened group one over
+// its 8 spheres.
 // Returns the filter tests (8 per step, at any level) this wave swept, for the lane-efficiency
 // counter; n_open counts the 8-record openings each ray itself needed.
 // ---------------------------------------------------------------------------------------
-constexpr int kGroupExitSteps = 2; // exit check every 16 super-groups
+constexpr int kGroupExitSteps = 2; // exit check every 16 hyper-groups
 template <typename FetchF, typename FetchE>
-DEVINL int anyhit_sph_groups_filter(FetchF recu, FetchF recg, FetchF recf, FetchE rece, int n_sup,
-                                    int base, f3 o, f3 L, const RayF &rf, bool far, Any &a,
+DEVINL int anyhit_sph_groups_filter(FetchF recy, FetchF recu, FetchF recg, FetchF recf, FetchE rece,
+                                    int n_hyp, int base, f3 o, f3 L, const RayF &rf, bool far, Any &a,
                                     int &n_open) {
   int swept = 0;
   const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
@@ -1596,27 +1641,39 @@ DEVINL int anyhit_sph_groups_filter(FetchF recu, FetchF recg, FetchF recf, Fetch
       swept += kSphGroup;
     }
   };
-  auto step = [&](const PairF(&U)[4], int s0) { // 8 super-groups
+  auto supers = [&](int y) { // the 8 super-groups = 4 pair records of hyper-group y
+    PairF U[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) U[i] = recu(4 * y + i);
     uint32_t mask = open_mask(U);
     while (mask) {
       const int j = __builtin_ctz(mask);
       mask &= mask - 1;
-      groups(s0 + j);
+      groups(8 * y + j);
       swept += kSphSuper;
     }
   };
-  for (int s0 = 0; s0 < n_sup; s0 += 8 * kGroupExitSteps) {
+  auto step = [&](const PairF(&Y)[4], int y0) { // 8 hyper-groups
+    uint32_t mask = open_mask(Y);
+    while (mask) {
+      const int j = __builtin_ctz(mask);
+      mask &= mask - 1;
+      supers(y0 + j);
+      swept += kSphHyper;
+    }
+  };
+  for (int y0 = 0; y0 < n_hyp; y0 += 8 * kGroupExitSteps) {
     if (!__builtin_amdgcn_ballot_w64(a.tb > 0.f)) return swept;
-    const int m = min(8 * kGroupExitSteps, n_sup - s0); // super-groups in this stretch, multiple of 8
+    const int m = min(8 * kGroupExitSteps, n_hyp - y0); // hyper-groups in this stretch, multiple of 8
     swept += m;
     PairF A[4], B[4];
-    fetch_batch(recu, s0 >> 1, A);
+    fetch_batch(recy, y0 >> 1, A);
     for (int g = 0; g < m; g += 16) {
-      fetch_batch(recu, recu.landed(A[3].k, (s0 + min(g + 8, m - 8)) >> 1), B);
-      step(A, s0 + g);
+      fetch_batch(recy, recy.landed(A[3].k, (y0 + min(g + 8, m - 8)) >> 1), B);
+      step(A, y0 + g);
       if (g + 8 >= m) break;
-      fetch_batch(recu, recu.landed(B[3].k, (s0 + min(g + 16, m - 8)) >> 1), A);
-      step(B, s0 + g + 8);
+      fetch_batch(recy, recy.landed(B[3].k, (y0 + min(g + 16, m - 8)) >> 1), A);
+      step(B, y0 + g + 8);
     }
   }
   return swept;

@@ -530,14 +530,17 @@ int commit(esc_context *ctx, const Staged &s) {
   std::vector<esc::DevSph> sg_sorted;
   std::vector<esc::DevSphGroup> sg_grp;
   std::vector<esc::DevIdx4> sg_orig;
-  size_t sg_n_grp = 0;
+  size_t sg_n_grp = 0, sg_n_sup = 0;
   if ((int)s.sph.size() >= esc::kSphGroupMinSpheres) {
     std::vector<int32_t> order;
     constexpr size_t kBig = (size_t)esc::kSphGroup * esc::kSphSuper; // spheres per super-group
-    esc::group_order(s.sph, esc::kSphGroup, (int)kBig, order);
+    constexpr size_t kHuge = kBig * esc::kSphHyper;                  // ... per hyper-group
+    esc::group_order(s.sph, esc::kSphGroup, (int)kBig, (int)kHuge, order);
     const size_t n_real = (s.sph.size() + esc::kSphGroup - 1) / esc::kSphGroup;
     const size_t n_sup_real = (s.sph.size() + kBig - 1) / kBig;
-    const size_t n_sup = (n_sup_real + esc::kSphGroupStep - 1) / esc::kSphGroupStep * esc::kSphGroupStep;
+    const size_t n_hyp_real = (s.sph.size() + kHuge - 1) / kHuge;
+    const size_t n_hyp = (n_hyp_real + esc::kSphGroupStep - 1) / esc::kSphGroupStep * esc::kSphGroupStep;
+    const size_t n_sup = n_hyp * esc::kSphHyper;
     const size_t n_grp = n_sup * esc::kSphSuper;
     esc::DevSph pad_s;
     pad_s.cx = pad_s.cy = pad_s.cz = 0.f;
@@ -546,7 +549,7 @@ int commit(esc_context *ctx, const Staged &s) {
     esc::DevSphGroup pad_g;
     pad_g.cx = pad_g.cy = pad_g.cz = 0.f;
     pad_g.rgeo = -1.f;
-    sg_grp.assign(n_grp + n_sup, pad_g); // groups, then super-groups
+    sg_grp.assign(n_grp + n_sup + n_hyp, pad_g); // groups, then super-groups, then hyper-groups
     esc::DevIdx4 pad_i;
     pad_i.v[0] = pad_i.v[1] = pad_i.v[2] = pad_i.v[3] = INT32_MAX / 2;
     sg_orig.assign(n_grp * esc::kSphGroup / 4, pad_i);
@@ -564,7 +567,13 @@ int commit(esc_context *ctx, const Staged &s) {
       sg_grp[n_grp + j] =
           esc::group_bounds(s.sph, order.data() + first, (int)std::min(kBig, order.size() - first));
     }
+    for (size_t j = 0; j < n_hyp_real; j++) {
+      const size_t first = j * kHuge;
+      sg_grp[n_grp + n_sup + j] =
+          esc::group_bounds(s.sph, order.data() + first, (int)std::min(kHuge, order.size() - first));
+    }
     sg_n_grp = n_grp;
+    sg_n_sup = n_sup;
   }
   // ... and the same groups for the last light's shadow rays: pair tables relative to g
   std::vector<esc::DevSphPair> sg_sorted2(sg_sorted.size() / 2);
@@ -618,14 +627,17 @@ int commit(esc_context *ctx, const Staged &s) {
   std::vector<esc::DevIdx4> tg_orig;
   std::vector<esc::DevTriPairF> tg_sorted2f;
   std::vector<esc::DevTriPairPF> tg_sorted2pf, tg_grp2pf;
-  size_t tg_n_grp = 0;
+  size_t tg_n_grp = 0, tg_n_sup = 0;
   if ((int)s.tri.size() >= esc::kTriGroupMinTris) {
     constexpr size_t kBig = (size_t)esc::kTriGroup * esc::kTriSuper;
+    constexpr size_t kHuge = kBig * esc::kTriHyper;
     std::vector<int32_t> order;
-    esc::group_order(s.tri, esc::kTriGroup, (int)kBig, order);
+    esc::group_order(s.tri, esc::kTriGroup, (int)kBig, (int)kHuge, order);
     const size_t n_real = (s.tri.size() + esc::kTriGroup - 1) / esc::kTriGroup;
     const size_t n_sup_real = (s.tri.size() + kBig - 1) / kBig;
-    const size_t n_sup = (n_sup_real + esc::kTriGroupStep - 1) / esc::kTriGroupStep * esc::kTriGroupStep;
+    const size_t n_hyp_real = (s.tri.size() + kHuge - 1) / kHuge;
+    const size_t n_hyp = (n_hyp_real + esc::kTriGroupStep - 1) / esc::kTriGroupStep * esc::kTriGroupStep;
+    const size_t n_sup = n_hyp * esc::kTriHyper;
     const size_t n_grp = n_sup * esc::kTriSuper;
     esc::DevTri pad_t;
     std::memset(&pad_t, 0, sizeof(pad_t));
@@ -633,7 +645,7 @@ int commit(esc_context *ctx, const Staged &s) {
     esc::DevTriGroup pad_g;
     std::memset(&pad_g, 0, sizeof(pad_g));
     pad_g.rgeo = -1.f;
-    tg_grp.assign(n_grp + n_sup, pad_g);
+    tg_grp.assign(n_grp + n_sup + n_hyp, pad_g);
     esc::DevIdx4 pad_i;
     pad_i.v[0] = pad_i.v[1] = pad_i.v[2] = pad_i.v[3] = INT32_MAX / 2;
     tg_orig.assign(n_grp * esc::kTriGroup / 4, pad_i);
@@ -651,7 +663,13 @@ int commit(esc_context *ctx, const Staged &s) {
       tg_grp[n_grp + j] =
           esc::tri_group_bounds(s.tri, order.data() + first, (int)std::min(kBig, order.size() - first));
     }
+    for (size_t j = 0; j < n_hyp_real; j++) {
+      const size_t first = j * kHuge;
+      tg_grp[n_grp + n_sup + j] =
+          esc::tri_group_bounds(s.tri, order.data() + first, (int)std::min(kHuge, order.size() - first));
+    }
     tg_n_grp = n_grp;
+    tg_n_sup = n_sup;
     tg_sorted2f = build_tri2f(tg_sorted);
     tg_sorted2pf = build_tri2pf(tg_sorted);
     tg_grp2pf.resize(tg_grp.size() / 2);
@@ -717,7 +735,8 @@ int commit(esc_context *ctx, const Staged &s) {
     if ((rc = alloc_dev(ctx->tg.sorted_pf, tg_sorted.size()))) return rc;
     if ((rc = alloc_dev(ctx->tg.grp_pf, tg_grp.size()))) return rc;
     ctx->tg.n_grp = (int32_t)tg_n_grp;
-    ctx->tg.n_sup = (int32_t)(tg_grp.size() - tg_n_grp);
+    ctx->tg.n_sup = (int32_t)tg_n_sup;
+    ctx->tg.n_hyp = (int32_t)(tg_grp.size() - tg_n_grp - tg_n_sup);
   }
   {
     esc::DevSphPair *d_s2 = const_cast<esc::DevSphPair *>(ctx->sg.sorted2);
@@ -744,7 +763,8 @@ int commit(esc_context *ctx, const Staged &s) {
     if ((rc = alloc_dev(ctx->sg.sorted_f, sg_sorted.size()))) return rc;
     if ((rc = alloc_dev(ctx->sg.grp_f, sg_grp.size()))) return rc;
     ctx->sg.n_grp = (int32_t)sg_n_grp;
-    ctx->sg.n_sup = (int32_t)(sg_grp.size() - sg_n_grp);
+    ctx->sg.n_sup = (int32_t)sg_n_sup;
+    ctx->sg.n_hyp = (int32_t)(sg_grp.size() - sg_n_grp - sg_n_sup);
   }
   if ((rc = upload_vec(ctx->d_sph2_ord, sph2o, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph2_f_ord, sph2fo, ctx->stream))) return rc;
@@ -1299,7 +1319,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     }();
     p.sg = ctx->sg;
     p.tg = ctx->tg;
-    if (index_order || env_nogroups) p.sg.n_grp = p.sg.n_sup = p.tg.n_grp = p.tg.n_sup = 0;
+    if (index_order || env_nogroups)
+      p.sg.n_grp = p.sg.n_sup = p.sg.n_hyp = p.tg.n_grp = p.tg.n_sup = p.tg.n_hyp = 0;
 
   }
   p.tri_f = ctx->d_tri_f;

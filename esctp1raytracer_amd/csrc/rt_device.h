@@ -89,8 +89,9 @@ struct alignas(16) DevSphPairF {
 // the image.
 // ---------------------------------------------------------------------------------------
 constexpr int kSphGroup = 8;          // spheres per group
-constexpr int kSphSuper = 8;          // groups per super-group (the level the sweeps start at)
-constexpr int kSphGroupStep = 8;      // super-groups per sweep step: n_sup is a multiple of this
+constexpr int kSphSuper = 8;          // groups per super-group
+constexpr int kSphHyper = 8;          // super-groups per hyper-group (the level the sweeps start at)
+constexpr int kSphGroupStep = 8;      // hyper-groups per sweep step: n_hyp is a multiple of this
 constexpr int kSphGroupMinSpheres = 64;
 struct alignas(16) DevSphGroup { // static: centre and the radius that holds every member sphere
   float cx, cy, cz, rgeo;        // pad group: rgeo < 0
@@ -98,25 +99,25 @@ struct alignas(16) DevSphGroup { // static: centre and the radius that holds eve
 struct alignas(16) DevIdx4 {
   int32_t v[4];
 };
-// Two levels: kSphSuper consecutive groups (64 spheres, one subtree of the k-d order) form a
-// super-group with its own bounding sphere, same record forms.  A sweep tests 8 super-groups per
-// step, opens the ones some ray of the wave may touch (one step over their 8 groups), and opens
-// groups from there.
+// Three levels: kSphSuper consecutive groups (64 spheres) form a super-group, kSphHyper
+// consecutive super-groups (512 spheres) a hyper-group, each a subtree of the k-d order with its
+// own bounding sphere in the same record forms.  A sweep tests 8 hyper-groups per step, opens the
+// ones some ray of the wave may touch (one step over their 8 super-groups), and so on down.
 struct SphGroups {
-  int32_t n_grp, n_sup;      // n_grp = 8 n_sup; 0: no groups (small scenes, ESC_RENDER_INDEX_ORDER,
-                             // filters off)
+  int32_t n_grp, n_sup;      // n_grp = 8 n_sup, n_sup = 8 n_hyp; 0: no groups (small scenes,
+  int32_t n_hyp, pad;        // ESC_RENDER_INDEX_ORDER, filters off)
   const DevSph *sorted;      // n_grp * kSphGroup spheres in group order; pad slots have r2 = -inf
-  const DevSphGroup *grp;    // n_grp, then the n_sup super-groups
+  const DevSphGroup *grp;    // n_grp groups, then the n_sup super-groups, then the n_hyp hyper-groups
   const DevIdx4 *orig;       // original index of each sorted slot, 4 per record; pads INT32_MAX / 2
   DevSphP *sorted_p;         // per frame: DevSphP / DevSphF of `sorted`, DevSphF of `grp`
   DevSphF *sorted_f;
-  DevSphF *grp_f;            // n_grp + n_sup
+  DevSphF *grp_f;            // n_grp + n_sup + n_hyp
   // shadow rays of the LAST light (any occluder will do there, rt_device.h sph2_ord): the same
   // sorted spheres and groups as pair tables, static per scene.  grp2_f holds the bounding spheres
   // in DevSphPairF form with R = rgeo + 0x1.6p-10 (rho_max + |C - g| + rgeo) (rt_brute.h).
   const DevSphPair *sorted2;    // n_grp * kSphGroup / 2 records
   const DevSphPairF *sorted2_f; // same
-  const DevSphPairF *grp2_f;    // n_grp / 2 records (pad groups: km = -inf), then n_sup / 2
+  const DevSphPairF *grp2_f;    // n_grp / 2 records (pad groups: km = -inf), then n_sup / 2, n_hyp / 2
 };
 
 // Triangles (rt_brute.h "FILTERS", triangle part).  The reference's numerators are scalar triple
@@ -194,8 +195,9 @@ struct DevLight {
 // parallel to ANY member has |d . a| <= kappa.  Static part per group:
 // ---------------------------------------------------------------------------------------
 constexpr int kTriGroup = 8;
-constexpr int kTriSuper = 16;
-constexpr int kTriGroupStep = 4; // super-groups per sweep step: n_sup is a multiple of this
+constexpr int kTriSuper = 16;    // groups per super-group (8: c5 22.9 ms, 16: 19.1, 32: 20.1 at the time)
+constexpr int kTriHyper = 8;     // super-groups per hyper-group (the level the sweeps start at)
+constexpr int kTriGroupStep = 4; // hyper-groups per sweep step: n_hyp is a multiple of this
 constexpr int kTriGroupMinTris = 64;
 struct alignas(16) DevTriGroup {
   float cx, cy, cz, rgeo; // rgeo >= |G_t - C| + 2 rho_t for every member (G_t centroid, rho_t its
@@ -206,10 +208,11 @@ struct alignas(16) DevTriGroup {
   float always;           // != 0: always open (a sliver among the members, or no useful cone)
 };
 struct TriGroups {
-  int32_t n_grp, n_sup;          // n_grp = 8 n_sup; 0: no groups
+  int32_t n_grp, n_sup;          // n_grp = kTriSuper n_sup, n_sup = kTriHyper n_hyp; 0: no groups
+  int32_t n_hyp, pad;
   const DevTri *sorted;          // n_grp * kTriGroup triangles in group order; pads are all zeros
   const DevIdx4 *orig;           // original index of each sorted slot, 4 per record
-  const DevTriGroup *grp;        // n_grp groups, then n_sup super-groups
+  const DevTriGroup *grp;        // n_grp groups, then n_sup super-groups, then n_hyp hyper-groups
   DevTriP *sorted_p;             // per frame: the forms of `sorted` ...
   DevTriF *sorted_f;
   DevTriPF *sorted_pf;
@@ -217,7 +220,7 @@ struct TriGroups {
   // shadow rays of the last light: static, two per record
   const DevTriPairPF *sorted2_pf;
   const DevTriPairF *sorted2_f;
-  const DevTriPairPF *grp2_pf;   // n_grp / 2 records, then n_sup / 2
+  const DevTriPairPF *grp2_pf;   // n_grp / 2 records, then n_sup / 2, then n_hyp / 2
 };
 
 // hand-over between k_primary and k_shade: the closest hit of every pixel of the band

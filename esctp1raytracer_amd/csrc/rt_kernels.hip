@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) k_prepare_groups(const SphGroups g, float
     g.sorted_p[i] = P;
     g.sorted_f[i] = F;
   }
-  if (i < g.n_grp + g.n_sup) { // groups, then super-groups: same form
+  if (i < g.n_grp + g.n_sup + g.n_hyp) { // groups, super-groups, hyper-groups: same form
     const DevSphGroup G = g.grp[i];
     DevSphF F;
     F.sx = F.sy = F.sz = F.w = 0.f; // pad group: never a candidate
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, f
   const f3 o = mk(ox, oy, oz);
   if (i < g.n_grp * kTriGroup)
     tri_primary_records(g.sorted[i], o, g.sorted_p[i], g.sorted_f[i], g.sorted_pf[i]);
-  if (i < g.n_grp + g.n_sup) {
+  if (i < g.n_grp + g.n_sup + g.n_hyp) {
     const DevTriGroup G = g.grp[i];
     DevTriPF Q;
     Q.sx = Q.sy = Q.sz = Q.w = 0.f; // pad group: never within reach ...
@@ -277,10 +277,12 @@ __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, f
         Q.w = F.w;
         // (P): only members whose plane the camera is within H_t of can be accepted through the
         // escape, and only by rays with |d . n_t| < beta_t.  The cone of THIS frame is therefore
-        // built over those members alone (8 or kTriGroup kTriSuper candidates; mostly none):
+        // built over those members alone (8, 128 or 1,024 candidates; mostly none):
         // axis a = mean of their unit normals, |d . a| <= beta_t + |d| |a x n_t| for each of them.
-        const int per = (i < g.n_grp) ? kTriGroup : kTriGroup * kTriSuper;
-        const int first = ((i < g.n_grp) ? i : (i - g.n_grp)) * per;
+        const int lvl = (i < g.n_grp) ? 0 : (i < g.n_grp + g.n_sup ? 1 : 2);
+        const int per = lvl == 0 ? kTriGroup
+                                 : (lvl == 1 ? kTriGroup * kTriSuper : kTriGroup * kTriSuper * kTriHyper);
+        const int first = (lvl == 0 ? i : (lvl == 1 ? i - g.n_grp : i - g.n_grp - g.n_sup)) * per;
         f3 acc = mk(0.f, 0.f, 0.f), ref = mk(0.f, 0.f, 0.f);
         float bmax = 0.f;
         int cnt = 0;
@@ -417,6 +419,15 @@ template <int PX> struct Tile {
 // per counter per workgroup into one of kCounterSets replicas (each on its own cache line).
 // 130k waves adding to four words of one line took longer than shading itself (4.7 ms).
 // Called by all 256 threads (barriers inside).  count_pixels: also add primary rays / hit pixels.
+// sum of a per-lane count over the wave, as a wave-uniform (SGPR) 64-bit value
+DEVINL unsigned long long wave_sum(uint32_t v) {
+  unsigned long long s = v;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)s);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(s >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 DEVINL void emit_counters(const RenderParams &p, int tid, int lane, bool inside, bool has_hit,
                           uint32_t n_shadow, unsigned long long n_any,
                           unsigned long long lane_tests_wave, bool count_pixels) {
@@ -551,11 +562,12 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     if constexpr (PX == 2) {
       if (p.use_filter && p.tg.n_grp > 0) {
         closest_tri_primary_groups(
+            SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp + p.tg.n_sup},
             SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp},
             SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf)},
             SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.sorted_pf)},
             SmemFetch<TriF>{reinterpret_cast<const TriF *>(p.tg.sorted_f)},
-            SmemFetch<DevTriP>{p.tg.sorted_p}, SmemFetch<DevIdx4>{p.tg.orig}, p.tg.n_sup, dv[0], hit);
+            SmemFetch<DevTriP>{p.tg.sorted_p}, SmemFetch<DevIdx4>{p.tg.orig}, p.tg.n_hyp, dv[0], hit);
       } else {
       const int n2 = (p.use_filter && p.n_tri >= 8) ? (p.n_tri & ~3) : 0;
       closest_tri_primary_filter(SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tri_pf)},
@@ -570,10 +582,11 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
       // multiples of 8 through the hand-scheduled packed bodies, the tail through the generic one
       if (p.use_filter && p.sg.n_grp > 0) {
         closest_sph_primary_groups(
+            SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp + p.sg.n_sup},
             SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp},
             SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f)},
             SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.sorted_f)},
-            SmemFetch<DevSphP>{p.sg.sorted_p}, SmemFetch<DevIdx4>{p.sg.orig}, p.sg.n_sup, p.n_tri,
+            SmemFetch<DevSphP>{p.sg.sorted_p}, SmemFetch<DevIdx4>{p.sg.orig}, p.sg.n_hyp, p.n_tri,
             dv[0], hit);
       } else {
       const int n8 = p.n_sph & ~7;
@@ -711,13 +724,16 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
   float r = 0.f, g = 0.f, b = 0.f; // vec3 default ctor, main.cpp:557-558
   const float nl = (float)p.n_lights;
   uint32_t n_shadow = 0;
-  unsigned long long n_any = 0; // any-hit tests the reference would have executed
+  // any-hit tests the reference would have executed: summed over the WAVE light by light (a
+  // per-lane 64-bit accumulator across the sweeps cost 12 B of scratch per lane)
+  unsigned long long n_any = 0;
   int n_swept = 0;              // primitives this WAVE swept in any-hit loops (x64 = lane-tests)
   for (int li = 0; li < p.n_lights; ++li) {
     const DevLight Lt = p.lights[li];
     Any a[1];
     int grp_open = 0; // 8-record openings of group sweeps this ray needed (counters only)
     bool tri_groups = false, sph_groups = false; // this light swept triangle / sphere groups
+    uint32_t cnt_lane = 0;                       // this ray's any-hit tests for this light
     f3 ro = N, rL = N; // shadow-ray origin (main.cpp:757 `hit`) and unit direction
     f3 lP = N;         // the light sample point and its index (light bins, ESC_STAGE_BVH)
     int lpt = 0;
@@ -778,7 +794,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
           bvh_trace<1, false>(p, ro, rL, s, walk, n_visits, n_tests, n_swept);
         a[0].kocc = (int32_t)s.key; // kNoKey -> -1
         a[0].tocc = s.thit;
-        n_any += (unsigned)n_tests;
+        cnt_lane = (uint32_t)n_tests;
       } else if constexpr (STAGE == STAGE_SMEM) {
         // ---- segments of the primitive list, undecided rays re-packed in between
         // (the LAST light sweeps the spheres by decreasing solid angle when the host built that
@@ -836,14 +852,18 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
               const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
               const RayF rs = make_ray_filter(so, sL, p.shadow_center);
               int n_open = 0;
-              // k0 sorted slots in = k0 / 8 groups = k0 / (8 kTriSuper) super-groups; two per pair record
+              // k0 sorted slots in = k0 / 8 groups = k0 / kPerSup super-groups = k0 / kPerHyp hyper-groups;
+              // two per pair record
+              constexpr int kPerSup = kTriGroup * kTriSuper, kPerHyp = kPerSup * kTriHyper;
               n_swept += anyhit_tri_groups_filter(
                   SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) +
-                                       (p.tg.n_grp >> 1) + k0 / (2 * kTriGroup * kTriSuper)},
+                                       ((p.tg.n_grp + p.tg.n_sup) >> 1) + k0 / (2 * kPerHyp)},
+                  SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) +
+                                       (p.tg.n_grp >> 1) + k0 / (2 * kPerSup)},
                   SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) + (k0 >> 4)},
                   SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.sorted2_pf) + (k0 >> 1)},
                   SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tg.sorted2_f) + (k0 >> 1)},
-                  SmemFetch<DevTri>{p.tg.sorted + k0}, n_here / (kTriGroup * kTriSuper), k0, so, sL, rs,
+                  SmemFetch<DevTri>{p.tg.sorted + k0}, n_here / kPerHyp, k0, so, sL, rs,
                   rt, far, aa,
                   n_open);
               if (rr >= 0 && n_open) R.n_open[rr] += n_open;
@@ -867,12 +887,14 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
                                fabsf(so.z - p.shadow_center[2]);
               const bool far = !(a1 <= p.shadow_rho_max); // also catches NaN
               int n_open = 0;
-              // k0 pair records in = k0 / 4 groups = k0 / 32 super-groups; two per record
+              // k0 pair records in = k0 / 4 groups = k0 / 32 super-groups = k0 / 256 hyper-groups; two per record
               n_swept += anyhit_sph_groups_filter(
+                  SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) +
+                                   ((p.sg.n_grp + p.sg.n_sup) >> 1) + (k0 >> 9)},
                   SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (p.sg.n_grp >> 1) + (k0 >> 6)},
                   SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (k0 >> 3)},
                   SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.sorted2_f) + k0},
-                  SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2) + k0}, n_here >> 5,
+                  SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2) + k0}, n_here >> 8,
                   p.n_tri + 2 * k0, so, sL, rf, far, aa[0], n_open);
               if (rr >= 0 && n_open) R.n_open[rr] += n_open;
             } else if (p.use_filter) {
@@ -933,17 +955,17 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
         n_shadow += 1u;
         // tests occlusion() runs for this ray: up to and including its first occluder
         if (STAGE != STAGE_BVH) {
-          // index-order sweeps: up to and including the occluder.  Group sweeps: the super-groups
-          // up to the occluder's (or all), 8 more filter tests per super-group / group this ray
-          // had opened.
+          // index-order sweeps: up to and including the occluder.  Group sweeps: the hyper-groups
+          // up to the occluder's (or all), 8 more filter tests per opening this ray needed.
           const int k = a[0].kocc;
           const bool by_tri = k >= 0 && k < p.n_tri;
-          unsigned cnt = tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper) + 1 : p.tg.n_sup)
+          unsigned cnt = tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper * kTriHyper) + 1
+                                                        : p.tg.n_hyp)
                                     : (unsigned)(by_tri ? k + 1 : p.n_tri);
           if (!by_tri)
-            cnt += sph_groups ? (unsigned)(k >= 0 ? ((k - p.n_tri) >> 6) + 1 : p.sg.n_sup)
+            cnt += sph_groups ? (unsigned)(k >= 0 ? ((k - p.n_tri) >> 9) + 1 : p.sg.n_hyp)
                               : (unsigned)(k >= 0 ? k - p.n_tri + 1 : p.n_sph);
-          n_any += cnt + 8u * (unsigned)grp_open;
+          cnt_lane = cnt + 8u * (unsigned)grp_open;
         }
       }
       if (p.shadows && a[0].kocc >= 0) {
@@ -966,6 +988,11 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
         }
       }
     }
+    if constexpr (STAGE == STAGE_SMEM) {
+      if (p.counters && p.shadows) n_any += wave_sum(cnt_lane); // wave-uniform
+    } else {
+      n_any += cnt_lane; // per lane (these variants have the registers)
+    }
   }
 
   if constexpr (STAGE == STAGE_SMEM) { // tile fields recomputed, not kept live (tile_again)
@@ -973,7 +1000,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
     const int tid_e = Te.wave * 64 + Te.lane;
     const bool inside_e = (Te.lr0 + Te.ly < p.n_local_rows) && (Te.h_tile + Te.ly < p.H) &&
                           (Te.w0 + Te.lx0 < p.W);
-    emit_counters(p, tid_e, Te.lane, inside_e, has_hit, n_shadow, n_any,
+    emit_counters(p, tid_e, Te.lane, inside_e, has_hit, n_shadow, Te.lane == 0 ? n_any : 0ull,
                   (unsigned long long)n_swept * 64ull, true);
     write_tile(p, Te, tid_e, r, g, b, inside_e, lds_px);
   } else {

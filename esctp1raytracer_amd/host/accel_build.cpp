@@ -490,16 +490,18 @@ void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, 
 
 // ---- sphere groups of the brute-force primary pass (rt_device.h SphGroups) ----------------
 // Spatial order by k-d median splits along the longest axis of the centres.  Every left part is a
-// whole number of `big` runs while more than one is left, and of `run`s below that, so consecutive
-// runs of `big` (super-groups) and of `run` (groups) in the result are subtrees.  Ties are broken by
+// whole number of `huge` runs while more than one is left, then of `big` runs, then of `run`s, so
+// consecutive runs of `huge` (hyper-groups), `big` (super-groups) and `run` (groups) in the result
+// are subtrees.  Ties are broken by
 // index: the order is a function of the scene alone.
-void group_order_points(const std::vector<float> &xyz, int run, int big, std::vector<int32_t> &order) {
+void group_order_points(const std::vector<float> &xyz, int run, int big, int huge,
+                        std::vector<int32_t> &order) {
   const size_t n_pts = xyz.size() / 3;
   order.resize(n_pts);
   std::iota(order.begin(), order.end(), 0);
   struct Split {
-    static void go(const float *xyz, int small, int big, int32_t *idx, size_t n) {
-      const int run = n > (size_t)big ? big : small;
+    static void go(const float *xyz, int small, int big, int huge, int32_t *idx, size_t n) {
+      const int run = n > (size_t)huge ? huge : (n > (size_t)big ? big : small);
       if (n <= (size_t)small) {
         std::sort(idx, idx + n);
         return;
@@ -521,29 +523,31 @@ void group_order_points(const std::vector<float> &xyz, int run, int big, std::ve
         const float ca = xyz[3 * (size_t)a + ax], cb = xyz[3 * (size_t)b + ax];
         return ca < cb || (ca == cb && a < b);
       });
-      go(xyz, small, big, idx, left);
-      go(xyz, small, big, idx + left, n - left);
+      go(xyz, small, big, huge, idx, left);
+      go(xyz, small, big, huge, idx + left, n - left);
     }
   };
-  Split::go(xyz.data(), run, big, order.data(), order.size());
+  Split::go(xyz.data(), run, big, huge, order.data(), order.size());
 }
 
-void group_order(const std::vector<DevSph> &sph, int run, int big, std::vector<int32_t> &order) {
+void group_order(const std::vector<DevSph> &sph, int run, int big, int huge,
+                 std::vector<int32_t> &order) {
   std::vector<float> xyz(3 * sph.size());
   for (size_t i = 0; i < sph.size(); i++) {
     xyz[3 * i + 0] = sph[i].cx;
     xyz[3 * i + 1] = sph[i].cy;
     xyz[3 * i + 2] = sph[i].cz;
   }
-  group_order_points(xyz, run, big, order);
+  group_order_points(xyz, run, big, huge, order);
 }
 
-void group_order(const std::vector<DevTri> &tri, int run, int big, std::vector<int32_t> &order) {
+void group_order(const std::vector<DevTri> &tri, int run, int big, int huge,
+                 std::vector<int32_t> &order) {
   std::vector<float> xyz(3 * tri.size());
   for (size_t i = 0; i < tri.size(); i++)
     for (int a = 0; a < 3; a++) // the centroid; non-finite coordinates sort somewhere, harmlessly
       xyz[3 * i + a] = tri[i].v0[a] + (tri[i].e1[a] + tri[i].e2[a]) * (1.f / 3.f);
-  group_order_points(xyz, run, big, order);
+  group_order_points(xyz, run, big, huge, order);
 }
 
 // Bounding sphere of the spheres order[first .. first + count): centre = middle of the box around

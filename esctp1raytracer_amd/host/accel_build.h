@@ -62,12 +62,14 @@ void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, 
                BuiltBvh &out);
 
 // Sphere groups of the brute-force passes (rt_device.h SphGroups): a spatial order whose
-// consecutive runs of `run` spheres (groups) and of `big` spheres (super-groups; a multiple of
-// `run`) are neighbours, and the bounding sphere of one run.
-void group_order(const std::vector<DevSph> &sph, int run, int big, std::vector<int32_t> &order);
+// consecutive runs of `run` spheres (groups), `big` (super-groups) and `huge` (hyper-groups; each a
+// multiple of the one before) are neighbours, and the bounding sphere of one run.
+void group_order(const std::vector<DevSph> &sph, int run, int big, int huge,
+                 std::vector<int32_t> &order);
 DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, int count);
 // The same for triangles (rt_device.h TriGroups): order over the centroids; a group's static record.
-void group_order(const std::vector<DevTri> &tri, int run, int big, std::vector<int32_t> &order);
+void group_order(const std::vector<DevTri> &tri, int run, int big, int huge,
+                 std::vector<int32_t> &order);
 DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *order, int count);
 
 } // namespace esc
