@@ -1010,7 +1010,29 @@ struct Any {
   float tb;
   float tocc;
   int32_t kocc;
+  // Group sweeps of a light that is NOT the last one (rt_device.h SphGroups / TriGroups): the next
+  // light's ray starts at the FIRST occluder in index order (quirk S3), and the groups are not
+  // swept in index order -- so such a sweep visits every group, keeps the ray looking, and
+  // records the accepted primitive with the LOWEST original index: `orig` (wave-uniform, else
+  // nullptr) maps a sorted slot, idx - orig_bias, to it; orig_add is n_tri for spheres.
+  const int32_t *orig;
+  int32_t orig_bias, orig_add;
 };
+// an accepted any-hit test of primitive idx (a sorted slot in the group sweeps) at distance t2
+DEVINL void any_accept(Any &a, int idx, float t2) {
+  if (a.orig) {
+    typedef const int32_t __attribute__((address_space(4))) *ConstI;
+    const int id = ((ConstI)(uintptr_t)a.orig)[idx - a.orig_bias] + a.orig_add; // scalar load
+    if (a.kocc < 0 || id < a.kocc) {
+      a.tocc = t2;
+      a.kocc = id;
+    }
+  } else {
+    a.tocc = t2;
+    a.kocc = idx;
+    a.tb = 0.f;
+  }
+}
 // Each check drains the fetch pipeline (the next block's s_load is re-issued cold), so it is
 // taken every 256 primitives, not more often: overshooting an exit by < 256 of 10^4..10^5
 // primitives costs far less than a cold scalar load per 32.
@@ -1052,11 +1074,8 @@ DEVINL void test_tri_any(const DevTri &T, int idx, const V3<V> (&o)[NV], const V
         Any &aa = a[j * LN + c];
         const float de = comp(det[j], c), u = comp(un[j], c), v = comp(vn[j], c);
         float t2, v2;
-        if (tri_candidate(de, u, v) && tri_exact(de, u, v, comp(tn, c), aa.tb, t2, v2)) {
-          aa.tocc = t2;
-          aa.kocc = idx;
-          aa.tb = 0.f;
-        }
+        if (tri_candidate(de, u, v) && tri_exact(de, u, v, comp(tn, c), aa.tb, t2, v2))
+          any_accept(aa, idx, t2);
       }
     }
   }
@@ -1584,11 +1603,8 @@ DEVINL int anyhit_sph_groups_filter(FetchF recy, FetchF recu, FetchF recg, Fetch
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         float t2;
-        if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2)) {
-          a.tocc = t2;
-          a.kocc = base + 2 * (k + i) + c; // position in the sorted table: never read (last light)
-          a.tb = 0.f;
-        }
+        if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2))
+          any_accept(a, base + 2 * (k + i) + c, t2); // a position in the sorted table
       }
   };
   auto members = [&](int g) { // the 8 spheres = 4 pair records of group g

@@ -1449,12 +1449,15 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   }();
   const int want = (opts->flags & ESC_RENDER_SHADE_QUEUE) ? 2
                    : (opts->flags & ESC_RENDER_SHADE_FUSED) ? 1 : shade_env;
-  // A single light's shadow rays sweep the primitive GROUPS (rt_device.h SphGroups / TriGroups),
-  // which only the fused form does: a grouped table then counts as nothing here.  With several
-  // lights all but the last sweep the whole list in index order, and the rule is the old one.
-  const bool one_light_groups = p.use_filter && p.n_lights == 1;
-  const int64_t eff_sph = (one_light_groups && p.sg.n_grp > 0) ? 0 : p.n_sph;
-  const int64_t eff_tri = (one_light_groups && p.tg.n_grp > 0) ? 0 : p.n_tri;
+  // Shadow rays sweep the primitive GROUPS (rt_device.h SphGroups / TriGroups) in the fused form
+  // only -- the last light in any order, earlier lights in "first occluder" mode as long as a
+  // table is one segment (2^20 records) -- so a grouped table counts as nothing here.
+  const bool sph_grouped = p.use_filter && p.sg.n_grp > 0 &&
+                           (p.n_lights == 1 || (int64_t)p.sg.n_grp * (esc::kSphGroup / 2) <= (1 << 20));
+  const bool tri_grouped = p.use_filter && p.tg.n_grp > 0 &&
+                           (p.n_lights == 1 || (int64_t)p.tg.n_grp * esc::kTriGroup <= (1 << 20));
+  const int64_t eff_sph = sph_grouped ? 0 : p.n_sph;
+  const int64_t eff_tri = tri_grouped ? 0 : p.n_tri;
   const bool queue_form =
       stage == 1 && p.shadows && p.n_lights > 0 && want != 1 &&
       (want == 2 || opts->stage == ESC_STAGE_AUTO) &&

@@ -740,6 +740,8 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
     a[0].tb = 0.f;
     a[0].tocc = 0.f;
     a[0].kocc = -1;
+    a[0].orig = nullptr;
+    a[0].orig_bias = a[0].orig_add = 0;
     if (has_hit) {
       int ww = w, hh = h;
       if constexpr (STAGE == STAGE_SMEM) { // not kept live across the sweeps (tile_again)
@@ -817,10 +819,16 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
         // triangles; 512, 512, 1024, ... pair records), which keeps the barriers few.
         // the last light sweeps the sphere GROUPS when the host built them (rt_device.h SphGroups):
         // k0 then counts pair records of the sorted table, 4 per group, segments whole steps
-        const bool grp = (li == p.n_lights - 1) && p.use_filter && p.sg.n_grp > 0;
+        // Lights before the last sweep the groups too, in "first occluder" mode (rt_brute.h Any:
+        // every group visited, the accepted primitive with the lowest original index kept) --
+        // as long as the whole table is one segment, which it is below 2^20 records.
+        const bool last_light = li == p.n_lights - 1;
+        const bool grp = p.use_filter && p.sg.n_grp > 0 &&
+                         (last_light || p.sg.n_grp * (kSphGroup / 2) <= kSegGroupPairs);
         const int n_rec = grp ? p.sg.n_grp * (kSphGroup / 2) : (p.n_sph + 1) >> 1;
         // ... and the triangle GROUPS (rt_device.h TriGroups): k0 counts sorted slots, 8 per group
-        const bool tgrp = TGRP && (li == p.n_lights - 1) && p.use_filter && p.tg.n_grp > 0;
+        const bool tgrp = TGRP && p.use_filter && p.tg.n_grp > 0 &&
+                          (last_light || p.tg.n_grp * kTriGroup <= kSegGroupPairs);
         const int n_tri_sweep = tgrp ? p.tg.n_grp * kTriGroup : p.n_tri;
         int k0 = 0, seg = tgrp ? kSegGroupPairs : kSegTris; // triangles first (index order)
         bool in_tris = p.n_tri > 0;
@@ -845,6 +853,8 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
             aa[0].tb = (rr >= 0) ? R.tb[rs] : 0.f;
             aa[0].tocc = 0.f;
             aa[0].kocc = -1;
+            aa[0].orig = nullptr;
+            aa[0].orig_bias = aa[0].orig_add = 0;
             const f3 so = mk(R.ox[rs], R.oy[rs], R.oz[rs]);
             const f3 sL = mk(R.lx[rs], R.ly[rs], R.lz[rs]);
             if (TGRP && in_tris && tgrp) {
@@ -852,6 +862,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
               const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
               const RayF rs = make_ray_filter(so, sL, p.shadow_center);
               int n_open = 0;
+              if (!last_light) aa[0].orig = reinterpret_cast<const int32_t *>(p.tg.orig); // bias, add 0
               // k0 sorted slots in = k0 / 8 groups = k0 / kPerSup super-groups = k0 / kPerHyp hyper-groups;
               // two per pair record
               constexpr int kPerSup = kTriGroup * kTriSuper, kPerHyp = kPerSup * kTriHyper;
@@ -887,6 +898,10 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
                                fabsf(so.z - p.shadow_center[2]);
               const bool far = !(a1 <= p.shadow_rho_max); // also catches NaN
               int n_open = 0;
+              if (!last_light) {
+                aa[0].orig = reinterpret_cast<const int32_t *>(p.sg.orig);
+                aa[0].orig_bias = aa[0].orig_add = p.n_tri;
+              }
               // k0 pair records in = k0 / 4 groups = k0 / 32 super-groups = k0 / 256 hyper-groups; two per record
               n_swept += anyhit_sph_groups_filter(
                   SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) +
@@ -920,9 +935,11 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
         __syncthreads();
         a[0].kocc = R.kocc[tid];
         a[0].tocc = R.tocc[tid];
-        if (grp || tgrp) grp_open = R.n_open[tid];
-        tri_groups = tgrp;
-        sph_groups = grp;
+        if (last_light) { // earlier lights report the reference's own count: their kocc is the
+          if (grp || tgrp) grp_open = R.n_open[tid]; // first occluder in index order
+          tri_groups = tgrp;
+          sph_groups = grp;
+        }
         rL = mk(R.lx[tid], R.ly[tid], R.lz[tid]); // not kept live across the segments
         N = mk(R.keep[0][tid], R.keep[1][tid], R.keep[2][tid]);
         r = R.keep[3][tid]; g = R.keep[4][tid]; b = R.keep[5][tid];
@@ -1097,6 +1114,8 @@ __global__ void __launch_bounds__(256) k_anyhit_segment(const RenderParams p, co
       aa[0].tb = 0.f;
       aa[0].tocc = 0.f;
       aa[0].kocc = -1;
+      aa[0].orig = nullptr;
+      aa[0].orig_bias = aa[0].orig_add = 0;
       f3 so = mk(0.f, 0.f, 0.f), sL = so;
       if (valid) {
         const ShadowRay R = p.sq.rays[id];
