@@ -756,12 +756,13 @@ DEVINL void closest_tri_primary_filter(FetchP recp, FetchF recf, FetchE rece, in
 
 // ---------------------------------------------------------------------------------------
 // Triangle GROUPS (rt_device.h TriGroups): the pre-filter's two statements, lifted from one
-// triangle to 8 (a group) and 64 (a super-group) that are neighbours in space.  For a member t the
-// pre-filter's proof gives: a reference accept has (S_t) the line through o'_t = v0 + tvec within
-// 2 rho_t of the centroid G_t, or (E_t) |det*| < tau_t.
+// triangle to 8 (a group), 128 (a super-group) and 1,024 (a hyper-group) that are neighbours in
+// space.  For a member t the pre-filter's proof gives: a reference accept has (S_t) the line
+// through o'_t = v0 + tvec within rho_t of a point of the triangle, or (E_t) |det*| < tau_t.
 //  (S_t): o'_t is within 1.01u |tvec_t|_1 of the camera o, C~ = o - fl(o - C) within 1.01u A of the
-//   stored centre C (A = |fl(o - C)|_1), |tvec_t|_1 <= (A + rext)(1 + 2u); with rgeo >= |G_t - C| +
-//   2 rho_t the line through o passes C~ within  R := rgeo + 8u (A + rext) + 2^-60, and (C, R) goes
+//   stored centre C (A = |fl(o - C)|_1), |tvec_t|_1 <= (A + rext)(1 + 2u); with rgeo >= rho_t +
+//   |v - C| for every vertex v of every member (a triangle is the convex hull of its vertices)
+//   the line through o passes C~ within  R := rgeo + 8u (A + rext) + 2^-60, and (C, R) goes
 //   through the scaled sphere record exactly as a sphere group's (C, R) does: |b''| >= 1.
 //  (E_t): |d . n_t| < tau_t / |n1_t| <= b0 + b1 |tvec_t|_1 for the unit normal n_t (tau_t's formula is
 //   linear in |tvec|: host, tri_group_bounds).  With a unit axis a and sin(angle(a, +-n_t)) <= smax:

@@ -200,8 +200,8 @@ constexpr int kTriHyper = 8;     // super-groups per hyper-group (the level the 
 constexpr int kTriGroupStep = 4; // hyper-groups per sweep step: n_hyp is a multiple of this
 constexpr int kTriGroupMinTris = 64;
 struct alignas(16) DevTriGroup {
-  float cx, cy, cz, rgeo; // rgeo >= |G_t - C| + 2 rho_t for every member (G_t centroid, rho_t its
-                          // bounding radius); rgeo < 0: pad group
+  float cx, cy, cz, rgeo; // rgeo >= rho_t + |v - C| for every vertex v of every member (rho_t: the
+                          // member's bounding radius about its centroid); rgeo < 0: pad group
   float ax, ay, az, smax; // unit axis; smax >= |a x n_t / |n_t|| for every member
   float rext;             // >= |v0_t - C|_1 + |e1_t|_1 + |e2_t|_1 for every member
   float b0, b1;           // tau_t / |n1_t| <= b0 + b1 |tvec_t|_1 for every member (rt_brute.h)

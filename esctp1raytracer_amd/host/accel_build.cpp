@@ -581,13 +581,13 @@ DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, i
 }
 
 // Static record of the triangles order[0 .. count) as one group (rt_device.h DevTriGroup), in
-// double, every bound rounded up.  Per member: centroid G, bounding radius rho around it, longest
+// double, every bound rounded up.  rgeo >= rho_t + max_v |v - C| over the members' vertices.  Per member: centroid G, bounding radius rho around it, longest
 // edge emax, n1 = e2 x e1; a member with rho <= 2^-9.9 emax (a sliver: the pre-filter passes those
 // on unconditionally) or without a normal makes the group `always` open.
 DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *order, int count) {
   const double u = 0x1p-24;
   struct M {
-    double G[3], rho, nh[3], b0, b1, ext[3], a12;
+    double G[3], rho, nh[3], b0, b1, ext[3], a12, vtx[3][3];
     bool bad;
   };
   std::vector<M> ms((size_t)count);
@@ -627,9 +627,13 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
     const double k = 3.2 * u * emax / (m.rho / 1.00002) / nn * 1.0001;
     m.b1 = k * (10.04 * a2 + 5.04 * a1);
     m.b0 = k * 20.1 * a1 * a2;
-    for (int a = 0; a < 3; a++) {
-      lo[a] = std::min(lo[a], m.G[a] - 2.0 * m.rho);
-      hi[a] = std::max(hi[a], m.G[a] + 2.0 * m.rho);
+    for (int a = 0; a < 3; a++) { // box of the vertices
+      const double x0 = t.v0[a], x1 = x0 + e1[a], x2 = x0 + e2[a];
+      lo[a] = std::min(lo[a], std::min(x0, std::min(x1, x2)));
+      hi[a] = std::max(hi[a], std::max(x0, std::max(x1, x2)));
+      m.vtx[0][a] = x0;
+      m.vtx[1][a] = x1;
+      m.vtx[2][a] = x2;
     }
   }
   DevTriGroup g;
@@ -655,8 +659,14 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
   const double C[3] = {g.cx, g.cy, g.cz};
   double rg = 0, rext = 0, b0 = 0, b1 = 0, ax[3] = {0, 0, 0};
   for (const M &m : ms) {
-    const double d[3] = {m.G[0] - C[0], m.G[1] - C[1], m.G[2] - C[2]};
-    rg = std::max(rg, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 2.0 * m.rho);
+    // (S_t): the accepted hit point lies within rho_t of the triangle, hence -- the triangle being
+    // the convex hull of its vertices -- within rho_t + max_v |v - C| of C
+    double far_v = 0;
+    for (int v = 0; v < 3; v++) {
+      const double d[3] = {m.vtx[v][0] - C[0], m.vtx[v][1] - C[1], m.vtx[v][2] - C[2]};
+      far_v = std::max(far_v, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+    }
+    rg = std::max(rg, far_v + m.rho);
     rext = std::max(rext, std::fabs(m.ext[0] - C[0]) + std::fabs(m.ext[1] - C[1]) +
                               std::fabs(m.ext[2] - C[2]) + m.a12);
     b0 = std::max(b0, m.b0);

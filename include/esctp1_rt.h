@@ -231,9 +231,10 @@ enum {
    * cannot be observed: from 64 spheres / 64 triangles up they sweep bounding spheres (and normal
    * cones) of spatial groups of 8 and open only the groups a ray of the wavefront may touch
    * (csrc/rt_device.h SphGroups / TriGroups) -- closest hits with the tie rule restated on the
-   * original index, shadow rays for the LAST light only (for the others the first occluder's t2
-   * moves the next light's ray, quirk S3, and index order is kept); shorter sphere lists of the
-   * last light are swept by decreasing solid angle.  Same image bit for bit, far fewer tests;
+   * original index; shadow rays of the LAST light stop at any occluder; shadow rays of earlier
+   * lights, whose FIRST occluder in index order moves the next light's ray (quirk S3), visit
+   * every group and keep the accepted primitive with the lowest original index.  Shorter sphere
+   * lists of the last light are swept by decreasing solid angle.  Same image bit for bit, far fewer tests;
    * esc_counters.anyhit_tests then counts what THIS order executed.  This flag switches all of
    * that off: index order everywhere, anyhit_tests == the reference's count. */
   ESC_RENDER_INDEX_ORDER = 4,
