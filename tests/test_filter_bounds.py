@@ -656,6 +656,34 @@ def _escape_possible(o, v0, e1, e2):
     return yes, bounded, nh, beta
 
 
+def _patch_groups(rng, n_grp, scale, size, offset=0.0):
+    """n_grp groups of 8 triangles: a 2 x 2 quad patch of y = bump(x, z), flat or curved, randomly
+    rotated and placed; static group records from the library (esc_tri_group_record, host only)"""
+    import ctypes as C
+    from esctp1raytracer_amd import _capi
+    lib = _capi.load()
+    gx, gz = np.meshgrid(np.arange(3), np.arange(3), indexing="ij")
+    rec = np.zeros((n_grp, 12), f32)
+    V0 = np.zeros((n_grp, 8, 3), f32)
+    E1 = np.zeros((n_grp, 8, 3), f32)
+    E2 = np.zeros((n_grp, 8, 3), f32)
+    for g in range(n_grp):
+        ph = rng.uniform(0, 6.3, 2)
+        amp = rng.choice([0.0, 0.05, 0.5])  # flat groups (coplanar members) included
+        P = np.stack([gx * size, amp * size * np.sin(gx * 0.8 + ph[0]) * np.cos(gz * 0.7 + ph[1]), gz * size], -1)
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        P = P @ Q.T + rng.uniform(-1, 1, 3) * scale + offset
+        a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+        tri = np.concatenate([np.stack([a, b, c], 2).reshape(-1, 3, 3), np.stack([a, c, d], 2).reshape(-1, 3, 3)])
+        tri = tri.astype(f32)
+        V0[g], E1[g], E2[g] = tri[:, 0], f32(tri[:, 1] - tri[:, 0]), f32(tri[:, 2] - tri[:, 0])
+        buf = np.ascontiguousarray(np.concatenate([V0[g], E1[g], E2[g]], axis=1), f32)
+        assert lib.esc_tri_group_record(buf.ctypes.data_as(C.POINTER(C.c_float)), 8,
+                                        rec[g].ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert (rec[:, 11] == 0).all()  # none is `always`
+    return rec, V0, E1, E2
+
+
 @pytest.mark.parametrize("scale,size,with_slab", [(1.0, 0.3, True), (30.0, 0.1, True), (30.0, 3.0, True),
                                                   (1000.0, 0.05, True), (30.0, 3.0, False)])
 def test_triangle_primary_group_never_rejects_a_member_candidate(scale, size, with_slab):
@@ -670,31 +698,9 @@ def test_triangle_primary_group_never_rejects_a_member_candidate(scale, size, wi
     scenario has the power to see the escape missing (with edges of a few units: for small
     triangles a det of rounding noise, ~u |e1||e2|, never clears the reference's absolute
     |det| > FLT_EPSILON)."""
-    import ctypes as C
-    from esctp1raytracer_amd import _capi
-    lib = _capi.load()
     rng = np.random.default_rng(int(scale * 3 + size * 100))
     n_grp, per = 6000, 60
-    # 8 triangles per group: a 2 x 2 quad patch of y = bump(x, z), randomly rotated and placed
-    gx, gz = np.meshgrid(np.arange(3), np.arange(3), indexing="ij")
-    rec = np.zeros((n_grp, 12), f32)
-    V0 = np.zeros((n_grp, 8, 3), f32)
-    E1 = np.zeros((n_grp, 8, 3), f32)
-    E2 = np.zeros((n_grp, 8, 3), f32)
-    for g in range(n_grp):
-        ph = rng.uniform(0, 6.3, 2)
-        amp = rng.choice([0.0, 0.05, 0.5])  # flat groups (coplanar members) included
-        P = np.stack([gx * size, amp * size * np.sin(gx * 0.8 + ph[0]) * np.cos(gz * 0.7 + ph[1]), gz * size], -1)
-        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
-        P = P @ Q.T + rng.uniform(-1, 1, 3) * scale
-        a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
-        tri = np.concatenate([np.stack([a, b, c], 2).reshape(-1, 3, 3), np.stack([a, c, d], 2).reshape(-1, 3, 3)])
-        tri = tri.astype(f32)
-        V0[g], E1[g], E2[g] = tri[:, 0], f32(tri[:, 1] - tri[:, 0]), f32(tri[:, 2] - tri[:, 0])
-        buf = np.ascontiguousarray(np.concatenate([V0[g], E1[g], E2[g]], axis=1), f32)
-        assert lib.esc_tri_group_record(buf.ctypes.data_as(C.POINTER(C.c_float)), 8,
-                                        rec[g].ctypes.data_as(C.POINTER(C.c_float))) == 0
-    assert (rec[:, 11] == 0).all()  # none is `always`
+    rec, V0, E1, E2 = _patch_groups(rng, n_grp, scale, size)
     n = n_grp * per
     gi = np.repeat(np.arange(n_grp), per)
     mi = rng.integers(0, 8, n)
@@ -790,5 +796,96 @@ def test_triangle_primary_group_never_rejects_a_member_candidate(scale, size, wi
         # triangles are so small for their distance that every accept is rounding noise)
         if scale / size < 1000:
             assert possible[~inplane & ~miss].mean() < 0.2
+    else:
+        assert missed.any()
+
+
+@pytest.mark.parametrize("scale,size,offset,cone", [(1.0, 0.3, 0.0, True), (30.0, 0.1, 0.0, True),
+                                                    (30.0, 3.0, 0.0, True), (30.0, 3.0, 400.0, True),
+                                                    (30.0, 3.0, 0.0, False)])
+def test_triangle_shadow_group_never_rejects_a_member_candidate(scale, size, offset, cone):
+    """rt_device.h TriGroups, shadow rays: commit()'s group record in DevTriPairPF form (bounding
+    sphere with R = rgeo + 8u at in the q' form, cone axis over kappa' = (smax + b0 + b1 at +
+    2^-20) 1.0001, at = rho_max + |C - g|_1 + rext) against the reference's any-hit accept of a
+    member, for origins inside the scene box -- on member planes and off them -- and rays that
+    hug member edges, run nearly in a member's plane, or lie IN it and pass the whole group by.
+    cone=False drops the cone part: the same rays must then lose candidates."""
+    rng = np.random.default_rng(int(scale * 5 + size * 70 + offset))
+    n_grp, per = 5000, 60
+    rec, V0, E1, E2 = _patch_groups(rng, n_grp, scale, size, offset)
+    n = n_grp * per
+    gi = np.repeat(np.arange(n_grp), per)
+    mi = rng.integers(0, 8, n)
+    v0, e1, e2 = V0[gi, mi], E1[gi, mi], E2[gi, mi]
+    nrm = np.cross(e1.astype(np.float64), e2.astype(np.float64))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    G = rec[gi]
+    Cg, rg = G[:, 0:3].astype(np.float64), G[:, 3:4].astype(np.float64)
+    o = rng.uniform(-1, 1, (n, 3)) * scale + offset
+    inplane = rng.uniform(size=n) < 0.5
+    hgt = ((o - v0) * nrm).sum(1, keepdims=True)
+    dist = np.linalg.norm(o - v0, axis=1, keepdims=True)
+    o = np.where(inplane[:, None], o - nrm * hgt + nrm * dist * rng.choice([-1, 1], (n, 1)) *
+                 10.0 ** rng.uniform(-9, -3, (n, 1)), o).astype(f32)
+    L = rays_near_edges(rng, o, v0, e1, e2, n)
+    graze = rng.uniform(size=n) < 0.5
+    dd = L.astype(np.float64)
+    dd = dd - nrm * (dd * nrm).sum(1, keepdims=True) * (1 - 10.0 ** rng.uniform(-9, -2, (n, 1)))
+    L = np.where(graze[:, None], unit(dd), L)
+    miss = rng.uniform(size=n) < 0.34  # origin and ray in the member's plane, passing the group by
+    t1 = np.cross(nrm, rng.normal(size=(n, 3)))
+    t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    t2 = np.cross(nrm, t1)
+    Cp = Cg - nrm * ((Cg - v0) * nrm).sum(1, keepdims=True)
+    om = Cp + t1 * rg * rng.uniform(3, 10, (n, 1))
+    aim = Cp + t2 * rg * rng.uniform(1.2, 3, (n, 1)) * rng.choice([-1, 1], (n, 1))
+    o = np.where(miss[:, None], om.astype(f32), o)
+    L = np.where(miss[:, None], unit(aim - o.astype(np.float64)), L)
+    Lx, Ly, Lz = L[:, 0], L[:, 1], L[:, 2]
+    # reference any-hit numerators (test_tri_any)
+    pv = ref_cross(Lx, Ly, Lz, e2[:, 0], e2[:, 1], e2[:, 2])
+    det = ref_dot(e1[:, 0], e1[:, 1], e1[:, 2], *pv)
+    tv = [f32(o[:, i] - v0[:, i]) for i in range(3)]
+    qv = ref_cross(*tv, e1[:, 0], e1[:, 1], e1[:, 2])
+    ref_ok = uv_accept(det, ref_dot(*tv, *pv), ref_dot(Lx, Ly, Lz, *qv))
+    # host side (commit()): g, rho_max over everything; the group record in double
+    pts = np.concatenate([V0.reshape(-1, 3), (V0 + E1).reshape(-1, 3), (V0 + E2).reshape(-1, 3),
+                          o]).astype(np.float64)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    g = (0.5 * (lo + hi)).astype(f32)
+    rho = 2.0 * np.maximum(hi - g, g - lo).sum() + 1e-30
+    c1 = np.abs(Cg - g.astype(np.float64)).sum(1)
+    at = rho + c1 + G[:, 8].astype(np.float64)
+    kappa = (G[:, 7].astype(np.float64) + G[:, 9] + G[:, 10].astype(np.float64) * at + 2.0 ** -20) * 1.0001
+    usable = kappa < 1.0
+    R = rg[:, 0] + 2.0 ** -21 * at + 2.0 ** -60
+    c = (Cg - g.astype(np.float64)).astype(f32)
+    c2 = (c.astype(np.float64) ** 2).sum(1)
+    R2 = R * R * 1.00001
+    km_d = R2 - c2 + 2.0 ** -16 * (c2 + R2) + 2.0 ** -120
+    km = km_d.astype(f32)
+    low = km.astype(np.float64) < km_d
+    km[low] = np.nextafter(km[low], f32(np.inf))
+    km = np.where(usable, km, f32(np.inf))
+    gv = np.where(usable[:, None], G[:, 4:7].astype(np.float64) / kappa[:, None], 0.0).astype(f32)
+    if not cone:
+        gv = np.full_like(gv, f32(2.0 ** 60))
+    cc = np.where(usable[:, None], c, f32(0))
+    # device side: make_ray_filter + tripair2_any_prefilter_pk
+    ax, ay, az = f32(o[:, 0] - g[0]), f32(o[:, 1] - g[1]), f32(o[:, 2] - g[2])
+    assert float((np.abs(ax) + np.abs(ay) + np.abs(az)).max()) <= rho  # none is `far`
+    nn = ref_dot(ax, ay, az, ax, ay, az)
+    ss = ref_dot(ax, ay, az, Lx, Ly, Lz)
+    nko = f32(nn * f32(-(1.0 - 2.0 ** -16)))
+    y = fma(cc[:, 2], f32(az + az), fma(cc[:, 1], f32(ay + ay), fma(cc[:, 0], f32(ax + ax), nko)))
+    x = fma(cc[:, 2], Lz, fma(cc[:, 1], Ly, fma(cc[:, 0], Lx, f32(-ss))))
+    with np.errstate(all="ignore"):
+        q = f32(fma(x, x, y) + km)
+        gg = fma(gv[:, 2], Lz, fma(gv[:, 1], Ly, f32(gv[:, 0] * Lx)))
+    opened = (q >= 0) | (np.abs(gg) <= 1)
+    assert ref_ok.sum() > n // 20 and (~ref_ok).sum() > n // 20
+    missed = ref_ok & ~opened
+    if cone:
+        assert not missed.any(), f"{int(missed.sum())} member accepts behind a closed group"
     else:
         assert missed.any()
