@@ -734,6 +734,7 @@ int commit(esc_context *ctx, const Staged &s) {
     if ((rc = alloc_dev(ctx->tg.sorted_f, tg_sorted.size()))) return rc;
     if ((rc = alloc_dev(ctx->tg.sorted_pf, tg_sorted.size()))) return rc;
     if ((rc = alloc_dev(ctx->tg.grp_pf, tg_grp.size()))) return rc;
+    if ((rc = alloc_dev(ctx->tg.esc, tg_grp.size()))) return rc;
     ctx->tg.n_grp = (int32_t)tg_n_grp;
     ctx->tg.n_sup = (int32_t)tg_n_sup;
     ctx->tg.n_hyp = (int32_t)(tg_grp.size() - tg_n_grp - tg_n_sup);
@@ -979,7 +980,7 @@ void esc_context_destroy(esc_context *ctx) {
                   const_cast<esc::DevTriPairPF *>(ctx->tg.sorted2_pf),
                   const_cast<esc::DevTriPairF *>(ctx->tg.sorted2_f),
                   const_cast<esc::DevTriPairPF *>(ctx->tg.grp2_pf), ctx->tg.sorted_p, ctx->tg.sorted_f,
-                  ctx->tg.sorted_pf, ctx->tg.grp_pf,
+                  ctx->tg.sorted_pf, ctx->tg.grp_pf, ctx->tg.esc,
                   ctx->d_sph_mat, ctx->d_mat,   ctx->d_lights,       ctx->d_light_points,
                   ctx->d_counters, ctx->d_img,  ctx->d_u8, ctx->d_hits, ctx->d_sq, ctx->d_sq_ctl,
                   ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_order,

@@ -207,6 +207,12 @@ struct alignas(16) DevTriGroup {
   float b0, b1;           // tau_t / |n1_t| <= b0 + b1 |tvec_t|_1 for every member (rt_brute.h)
   float always;           // != 0: always open (a sliver among the members, or no useful cone)
 };
+// the frame's cone of one node (k_prepare_tri_groups / k_prepare_tri_merge): state 0 = no member
+// below can take the escape, 1 = those that can have |d . a| <= beta + |d| s, 2 = nothing can be said
+struct alignas(8) DevTriEsc {
+  float ax, ay, az, s, beta;
+  int32_t state;
+};
 struct TriGroups {
   int32_t n_grp, n_sup;          // n_grp = kTriSuper n_sup, n_sup = kTriHyper n_hyp; 0: no groups
   int32_t n_hyp, pad;
@@ -216,7 +222,8 @@ struct TriGroups {
   DevTriP *sorted_p;             // per frame: the forms of `sorted` ...
   DevTriF *sorted_f;
   DevTriPF *sorted_pf;
-  DevTriPF *grp_pf;              // ... and of the groups / super-groups
+  DevTriPF *grp_pf;              // ... and of the groups / super-groups / hyper-groups
+  DevTriEsc *esc;                // per frame: the cone of every node (same indexing as grp)
   // shadow rays of the last light: static, two per record
   const DevTriPairPF *sorted2_pf;
   const DevTriPairF *sorted2_f;

@@ -249,84 +249,143 @@ DEVINL TriEscape tri_escape(const DevTri &T, f3 o) {
 }
 
 // per-frame records of the triangle groups (rt_device.h TriGroups): the sorted triangles' forms,
-// and every group's / super-group's record in pre-filter form (rt_brute.h "Triangle GROUPS")
+// and every group's / super-group's / hyper-group's record in pre-filter form (rt_brute.h
+// "Triangle GROUPS").  Three launches: level 0 builds each group's cone of THIS frame from its 8
+// members (statement (P): only members whose plane the camera is within H_t of can be accepted
+// through the escape, and only by rays with |d . n_t| < beta_t); levels 1 and 2 merge their
+// children's cones: for a child cone (a_c, s_c, beta_c) -- every flagged member t below it has
+// |d . a_c| <= beta_t + |d| s_c -- and a parent axis a_p, |d . a_p| <= beta_t + |d| (s_c + |a_p x a_c|).
+DEVINL DevTriPF tri_group_record(const DevTriGroup &G, f3 o, const DevTriEsc &E) {
+  DevTriPF Q;
+  Q.sx = Q.sy = Q.sz = Q.w = 0.f; // pad group: never within reach ...
+  Q.gx = 0x1p60f;                 // ... and never "nearly parallel" (|d.x| <= 2^-60 opens pads: harmless)
+  Q.gy = Q.gz = Q.pad = 0.f;
+  if (G.rgeo < 0.f) return Q;
+  Q.w = 2.f; // always open ...
+  Q.gx = 0.f;
+  if (G.always != 0.f) return Q; // ... unless the static bounds are usable
+  const f3 oc = o - mk(G.cx, G.cy, G.cz);
+  const float A = (fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z);
+  const float at = A + G.rext; // >= |tvec_t|_1 for every member
+  const float R = (G.rgeo + 0x1p-21f * at) + 0x1p-60f;
+  const float R2 = R * R * 1.00001f;
+  const DevSphF F = sphere_filter_record(oc, dot(oc, oc) - R2, R2);
+  Q.sx = F.sx;
+  Q.sy = F.sy;
+  Q.sz = F.sz;
+  Q.w = F.w;
+  if (E.state == 0) {
+    Q.gx = 0x1p60f; // no ray of this frame can take the escape here
+  } else if (E.state == 1) {
+    // 1e-5: the fp32 normals and axes; 2^-20: the FMA chain of g'' and |d| - 1
+    const float kp = (((E.s + 1e-5f) * 1.0001f + E.beta) + 0x1p-20f) * 1.0001f;
+    if (kp < 1.f) {
+      const float ik = 1.f / kp;
+      Q.gx = E.ax * ik;
+      Q.gy = E.ay * ik;
+      Q.gz = E.az * ik;
+    }
+  } // state 2: g'' = 0, always "nearly parallel"
+  return Q;
+}
+
 __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, float ox, float oy, float oz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const f3 o = mk(ox, oy, oz);
   if (i < g.n_grp * kTriGroup)
     tri_primary_records(g.sorted[i], o, g.sorted_p[i], g.sorted_f[i], g.sorted_pf[i]);
-  if (i < g.n_grp + g.n_sup + g.n_hyp) {
-    const DevTriGroup G = g.grp[i];
-    DevTriPF Q;
-    Q.sx = Q.sy = Q.sz = Q.w = 0.f; // pad group: never within reach ...
-    Q.gx = 0x1p60f;                 // ... and never "nearly parallel" (|d.x| <= 2^-60 opens pads: harmless)
-    Q.gy = Q.gz = Q.pad = 0.f;
-    if (!(G.rgeo < 0.f)) {
-      Q.w = 2.f; // always open ...
-      Q.gx = 0.f;
-      if (G.always == 0.f) { // ... unless the static bounds are usable
-        const f3 oc = o - mk(G.cx, G.cy, G.cz);
-        const float A = (fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z);
-        const float at = A + G.rext; // >= |tvec_t|_1 for every member
-        const float R = (G.rgeo + 0x1p-21f * at) + 0x1p-60f;
-        const float R2 = R * R * 1.00001f;
-        const DevSphF F = sphere_filter_record(oc, dot(oc, oc) - R2, R2);
-        Q.sx = F.sx;
-        Q.sy = F.sy;
-        Q.sz = F.sz;
-        Q.w = F.w;
-        // (P): only members whose plane the camera is within H_t of can be accepted through the
-        // escape, and only by rays with |d . n_t| < beta_t.  The cone of THIS frame is therefore
-        // built over those members alone (8, 128 or 1,024 candidates; mostly none):
-        // axis a = mean of their unit normals, |d . a| <= beta_t + |d| |a x n_t| for each of them.
-        const int lvl = (i < g.n_grp) ? 0 : (i < g.n_grp + g.n_sup ? 1 : 2);
-        const int per = lvl == 0 ? kTriGroup
-                                 : (lvl == 1 ? kTriGroup * kTriSuper : kTriGroup * kTriSuper * kTriHyper);
-        const int first = (lvl == 0 ? i : (lvl == 1 ? i - g.n_grp : i - g.n_grp - g.n_sup)) * per;
-        f3 acc = mk(0.f, 0.f, 0.f), ref = mk(0.f, 0.f, 0.f);
-        float bmax = 0.f;
-        int cnt = 0;
-        bool unbounded = false;
-        for (int m = 0; m < per; ++m) {
-          const TriEscape E = tri_escape(g.sorted[first + m], o);
+  if (i < g.n_grp) {
+    DevTriEsc N;
+    N.ax = N.ay = N.az = N.s = N.beta = 0.f;
+    N.state = 0;
+    f3 acc = mk(0.f, 0.f, 0.f), ref = mk(0.f, 0.f, 0.f);
+    int cnt = 0;
+    for (int m = 0; m < kTriGroup; ++m) {
+      const TriEscape E = tri_escape(g.sorted[i * kTriGroup + m], o);
+      if (!E.possible) continue;
+      if (!E.bounded) {
+        N.state = 2;
+        break;
+      }
+      if (cnt == 0) ref = E.nh;
+      acc = acc + E.nh * ((dot(E.nh, ref) < 0.f) ? -1.f : 1.f);
+      N.beta = fmaxf(N.beta, E.beta);
+      ++cnt;
+    }
+    if (N.state != 2 && cnt > 0) {
+      const float an = sqrtf(dot(acc, acc));
+      if (!(an > 0.5f * (float)cnt)) {
+        N.state = 2; // no useful axis
+      } else {
+        const f3 ax = acc * (1.f / an);
+        float smax = 0.f;
+        for (int m = 0; m < kTriGroup; ++m) {
+          const TriEscape E = tri_escape(g.sorted[i * kTriGroup + m], o);
           if (!E.possible) continue;
-          if (!E.bounded) {
-            unbounded = true;
-            break;
-          }
-          if (cnt == 0) ref = E.nh;
-          acc = acc + E.nh * ((dot(E.nh, ref) < 0.f) ? -1.f : 1.f);
-          bmax = fmaxf(bmax, E.beta);
-          ++cnt;
+          const f3 c = cross(ax, E.nh);
+          smax = fmaxf(smax, sqrtf(dot(c, c)));
         }
-        const float an = sqrtf(dot(acc, acc));
-        if (!unbounded && cnt > 0 && !(an > 0.5f * (float)cnt)) unbounded = true; // no useful axis
-        if (unbounded) {
-          // g'' = 0: always "nearly parallel" (Q.g* are 0)
-        } else if (cnt == 0) {
-          Q.gx = 0x1p60f; // no ray of this frame can take the escape here
-        } else {
-          const f3 ax = acc * (1.f / an);
-          float smax = 0.f;
-          for (int m = 0; m < per; ++m) {
-            const TriEscape E = tri_escape(g.sorted[first + m], o);
-            if (!E.possible) continue;
-            const f3 c = cross(ax, E.nh);
-            smax = fmaxf(smax, sqrtf(dot(c, c)));
-          }
-          // 1e-5: the fp32 normals and axis; 2^-20: the FMA chain of g'' and |d| - 1
-          const float kp = (((smax + 1e-5f) * 1.0001f + bmax) + 0x1p-20f) * 1.0001f;
-          if (kp < 1.f) {
-            const float ik = 1.f / kp;
-            Q.gx = ax.x * ik;
-            Q.gy = ax.y * ik;
-            Q.gz = ax.z * ik;
-          }
-        }
+        N.ax = ax.x;
+        N.ay = ax.y;
+        N.az = ax.z;
+        N.s = smax;
+        N.state = 1;
       }
     }
-    g.grp_pf[i] = Q;
+    g.esc[i] = N;
+    g.grp_pf[i] = tri_group_record(g.grp[i], o, N);
   }
+}
+
+// level 1 (super-groups from groups) and level 2 (hyper-groups from super-groups)
+__global__ void __launch_bounds__(256) k_prepare_tri_merge(const TriGroups g, int level, float ox, float oy,
+                                                           float oz) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = level == 1 ? g.n_sup : g.n_hyp;
+  if (j >= n) return;
+  const int fan = level == 1 ? kTriSuper : kTriHyper;
+  const int child0 = (level == 1 ? 0 : g.n_grp) + j * fan; // children are consecutive nodes
+  const int self = (level == 1 ? g.n_grp : g.n_grp + g.n_sup) + j;
+  DevTriEsc N;
+  N.ax = N.ay = N.az = N.s = N.beta = 0.f;
+  N.state = 0;
+  f3 acc = mk(0.f, 0.f, 0.f), ref = mk(0.f, 0.f, 0.f);
+  int cnt = 0;
+  for (int c = 0; c < fan; ++c) {
+    const DevTriEsc E = g.esc[child0 + c];
+    if (E.state == 0) continue;
+    if (E.state == 2) {
+      N.state = 2;
+      break;
+    }
+    const f3 a = mk(E.ax, E.ay, E.az);
+    if (cnt == 0) ref = a;
+    acc = acc + a * ((dot(a, ref) < 0.f) ? -1.f : 1.f);
+    N.beta = fmaxf(N.beta, E.beta);
+    ++cnt;
+  }
+  if (N.state != 2 && cnt > 0) {
+    const float an = sqrtf(dot(acc, acc));
+    if (!(an > 0.5f * (float)cnt)) {
+      N.state = 2;
+    } else {
+      const f3 ax = acc * (1.f / an);
+      float smax = 0.f;
+      for (int c = 0; c < fan; ++c) {
+        const DevTriEsc E = g.esc[child0 + c];
+        if (E.state != 1) continue;
+        const f3 x = cross(ax, mk(E.ax, E.ay, E.az));
+        smax = fmaxf(smax, (sqrtf(dot(x, x)) + E.s) * 1.0001f + 1e-6f);
+      }
+      N.ax = ax.x;
+      N.ay = ax.y;
+      N.az = ax.z;
+      N.s = smax;
+      N.state = smax < 1.f ? 1 : 2;
+    }
+  }
+  g.esc[self] = N;
+  g.grp_pf[self] = tri_group_record(g.grp[self], mk(ox, oy, oz), N);
 }
 
 // same hoisting for the leaf blocks of the acceleration structure (one thread per block slot)
@@ -1326,9 +1385,14 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
   hipLaunchKernelGGL(esc::k_prepare_primary, dim3((n + 255) / 256), dim3(256), 0, stream, p->tri,
                      tri_p, tri_f, tri_pf, p->n_tri, p->sph, sph_p, sph_f, p->n_sph, p->origin[0],
                      p->origin[1], p->origin[2]);
-  if (tg->n_grp > 0)
+  if (tg->n_grp > 0) {
     hipLaunchKernelGGL(esc::k_prepare_tri_groups, dim3((tg->n_grp * esc::kTriGroup + 255) / 256),
                        dim3(256), 0, stream, *tg, p->origin[0], p->origin[1], p->origin[2]);
+    hipLaunchKernelGGL(esc::k_prepare_tri_merge, dim3((tg->n_sup + 255) / 256), dim3(256), 0, stream,
+                       *tg, 1, p->origin[0], p->origin[1], p->origin[2]);
+    hipLaunchKernelGGL(esc::k_prepare_tri_merge, dim3((tg->n_hyp + 255) / 256), dim3(256), 0, stream,
+                       *tg, 2, p->origin[0], p->origin[1], p->origin[2]);
+  }
   if (sg->n_grp > 0)
     hipLaunchKernelGGL(esc::k_prepare_groups, dim3((sg->n_grp * esc::kSphGroup + 255) / 256),
                        dim3(256), 0, stream, *sg, p->origin[0], p->origin[1], p->origin[2]);
