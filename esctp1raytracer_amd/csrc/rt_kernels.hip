@@ -594,7 +594,11 @@ DEVINL Tile<1> tile_again(const RenderParams &p) {
   return T;
 }
 
-template <int STAGE, typename V, int NV>
+// GRP: the frame sweeps primitive groups (rt_device.h SphGroups / TriGroups).  The variant without
+// them (small scenes, ESC_RENDER_INDEX_ORDER, ESC_RENDER_EXACT_ONLY) is its own instantiation so
+// that the linear loops keep their registers (with both in one kernel the linear triangle loop of
+// c5 went from 427 to 507 ms).
+template <int STAGE, typename V, int NV, bool GRP = false>
 __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   constexpr int PX = NV * lanes_of<V>::n; // pixels per work-item
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
@@ -619,7 +623,7 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   pack3<V, NV>(dir, dv);
   if (STAGE == STAGE_SMEM) {
     if constexpr (PX == 2) {
-      if (p.use_filter && p.tg.n_grp > 0) {
+      if (GRP && p.use_filter && p.tg.n_grp > 0) {
         closest_tri_primary_groups(
             SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp + p.tg.n_sup},
             SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp},
@@ -639,7 +643,7 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     }
     if constexpr (PX == 2) {
       // multiples of 8 through the hand-scheduled packed bodies, the tail through the generic one
-      if (p.use_filter && p.sg.n_grp > 0) {
+      if (GRP && p.use_filter && p.sg.n_grp > 0) {
         closest_sph_primary_groups(
             SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp + p.sg.n_sup},
             SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp},
@@ -1435,7 +1439,12 @@ static void launch_primary(const esc::RenderParams *p, hipStream_t stream) {
   const int tw = 32 * NV * esc::lanes_of<V>::n;
   const int tiles_x = (p->W + tw - 1) / tw;
   const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
-  hipLaunchKernelGGL((esc::k_primary<STAGE, V, NV>), dim3(tiles_x * tiles_y), dim3(256), 0, stream, *p);
+  if (STAGE == esc::STAGE_SMEM && NV * esc::lanes_of<V>::n == 2 && p->use_filter &&
+      (p->sg.n_grp > 0 || p->tg.n_grp > 0))
+    hipLaunchKernelGGL((esc::k_primary<STAGE, V, NV, true>), dim3(tiles_x * tiles_y), dim3(256), 0, stream,
+                       *p);
+  else
+    hipLaunchKernelGGL((esc::k_primary<STAGE, V, NV>), dim3(tiles_x * tiles_y), dim3(256), 0, stream, *p);
 }
 
 // the queue form of the shadow pass for one light: setup, one launch per segment, finish.
