@@ -314,6 +314,12 @@ def main():
         streams.append(stb)
 
     events = []
+    # every event a step needs exists before the timed region (at N = 8 a rank's share of the
+    # frame is ~0.1 ms: the host side of a step must not be the slower half)
+    pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            for _ in range(a.steps + a.warmup + 8)]
+    free_ev = [torch.cuda.Event() for _ in range(n_buf)]
+    pool_next = [0]
 
     def step(i, timed):
         b = i % n_buf
@@ -321,8 +327,12 @@ def main():
         with torch.cuda.stream(ss):
             if buf_free[b] is not None:
                 ss.wait_event(buf_free[b])
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
+            if pool_next[0] < len(pool):
+                e0, e1 = pool[pool_next[0]]
+                pool_next[0] += 1
+            else:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
             e0.record(ss)
             rr.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
                              out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows,
@@ -338,7 +348,7 @@ def main():
                     r2.assemble_strips(gathered[b], world, n_local * local[b].element_size(), W, H,
                                        frame, strip_rows=S,
                                        bytes_per_pixel=3 * local[b].element_size())
-                ev = torch.cuda.Event()
+                ev = free_ev[b]  # its previous record has been waited on by this step's render
                 ev.record(st2)
                 buf_free[b] = ev
 

@@ -445,6 +445,36 @@ def test_triangle_groups_vs_oracle(esc, renderer, case):
         assert ref.sum() > 0
 
 
+def test_groups_on_large_tables_vs_oracle(esc, renderer):
+    """Many hyper-groups of both kinds in one scene -- 150,000 spheres and a 120,000-triangle
+    mesh (294 + 118 hyper-groups, partly filled last ones, pad records up to whole sweep steps),
+    two lights (the first swept in first-occluder mode) -- on a small frame: == oracle bit for
+    bit, == index order."""
+    rng = np.random.default_rng(2024)
+    n = 150_000
+    sph = np.concatenate([rng.uniform(-8, 8, (n, 1)), rng.uniform(0.3, 6, (n, 1)),
+                          rng.uniform(-20, -2, (n, 1)), rng.uniform(0.01, 0.05, (n, 1))], 1)
+    mats = np.tile(ol.material13(ka=(0.5, 0.6, 0.7), kd=(0.5, 0.6, 0.7)), (n, 1))
+    mesh = _grid_mesh(300, 200, -12, 12, -24, 4, lambda X, Z: 0.25 * np.sin(1.1 * X) * np.cos(0.8 * Z))
+    l1 = np.array([[-0.5, 12, -9.5], [0, 12, -10.5], [0.5, 12, -9.5]], float)
+    l2 = np.array([[6, 9, -2], [6.5, 9, -2], [6, 9.5, -2.3]], float)
+    geoms = [{"vertex": mesh.reshape(-1, 3).astype(np.float32),
+              "face_index": np.arange(3 * len(mesh)).reshape(-1, 3), "material": ol.WHITE}]
+    for lt in (l1, l2):
+        geoms.append({"vertex": lt.astype(np.float32), "face_index": np.array([[0, 1, 2]]),
+                      "material": ol.LIGHT_A})
+    d = ol.scene_dict(geoms, sph.astype(np.float32), mats)
+    eye, look = esc.synthetic_view()
+    W, H = 96, 54
+    gpu, u8, ref = render_both(esc, renderer, d, eye, look, W, H)
+    assert_bit_equal(gpu, ref, "large tables")
+    assert np.array_equal(u8, ol.oracle_quantise(ref))
+    cam = esc.Camera.for_image(eye, look, W, H)
+    other = renderer.render(cam, W, H, flags=esc.ESC_RENDER_INDEX_ORDER)
+    assert_bit_equal(other, ref, "large tables / index order")
+    assert ref.sum() > 0
+
+
 @pytest.mark.parametrize("form", ["queue", "fused"])
 def test_both_shading_forms_on_small_frames(esc, renderer, form):
     """The queue form is chosen by default only for long primitive lists on large bands; force
