@@ -299,6 +299,7 @@ def main():
             gathered = [torch.zeros(world, n_local, dtype=ch_dtype, device=dev) for _ in range(n_buf)]
             frame = torch.zeros(H * W * 3, dtype=ch_dtype, device=dev)
             r2 = esc.Renderer(local_rank, stream=st2)
+    gather_lists = [list(g.unbind(0)) for g in gathered] if gathered is not None else None
     buf_free = [None] * n_buf  # event: the gather that last read local[b] has finished
     # N>1: consecutive frames also alternate between TWO render contexts / streams.  A rank's
     # share of the frame is a small grid (N=8: 2,040 + 4,080 workgroups) whose last workgroups
@@ -343,7 +344,8 @@ def main():
         if world > 1:
             with torch.cuda.stream(st2):
                 st2.wait_event(e1)  # the collective orders itself after the current stream
-                multigpu.gather_to_root(local[b], rank, world, gathered[b] if rank == 0 else None)
+                multigpu.gather_to_root(local[b], rank, world, gathered[b] if rank == 0 else None,
+                                        gather_list=gather_lists[b] if rank == 0 else None)
                 if rank == 0:
                     r2.assemble_strips(gathered[b], world, n_local * local[b].element_size(), W, H,
                                        frame, strip_rows=S,
@@ -399,14 +401,19 @@ def main():
     # the reference's any-hit count: one frame in index order (the default sweeps long sphere lists
     # in another order for the last light and so executes fewer tests; the image is the same)
     anyhit_index_order = None
+    index_order_ms = None
     if world == 1 and a.stage != "bvh" and not a.profile_run:
         r.synchronize()
         r.reset_counters()
+        ei0, ei1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(st):
+            ei0.record(st)
             r.render_strips(cam, W, H, 0, 1, out_f32=None if use_u8 else local[0],
                             out_u8=local[0] if use_u8 else None, strip_rows=S, shadows=shadows,
                             stage=stage, flags=esc.ESC_RENDER_INDEX_ORDER)
+            ei1.record(st)
         anyhit_index_order = r.counters()["anyhit_tests"]
+        index_order_ms = ei0.elapsed_time(ei1)
         r.reset_counters()
     # one un-pipelined frame: launch -> complete frame resident on rank 0
     fence()
@@ -491,6 +498,12 @@ def main():
                             f"{info['n_lights']} light, 1 primary ray/pixel + "
                             f"{'1 shadow ray per hit pixel' if shadows else 'no shadow rays'}, "
                             f"{'bounding-volume tree (opt-in)' if a.stage == 'bvh' else 'brute force'}",
+                "sweep": ("every (ray, primitive) pair is decided by the reference arithmetic or by a proven "
+                          "conservative filter; from 64 primitives up the filters run on bounding spheres / "
+                          "normal cones of spatial groups of 8, 64-128 and 512-1,024 primitives first "
+                          "(DESIGN.md 3.6-3.7).  index_order_frame_ms = the same frame swept linearly in the "
+                          "reference's index order (ESC_RENDER_INDEX_ORDER), one frame, same run"),
+                "index_order_frame_ms": index_order_ms,
                 "scene": "esc_scene_synthetic (SURVEY.md 8(d)): splitmix64 seeds 0xC2..0xC4",
                 "partition": f"{S}-row strips round-robin over {world} rank(s)",
                 "gather": ("none (1 GPU)" if world == 1 else

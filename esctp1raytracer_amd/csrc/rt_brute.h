@@ -1217,8 +1217,9 @@ DEVINL void anyhit_tri_filter(FetchP recp, FetchF recf, FetchE rece, int n, int 
   }
 }
 
-// Triangle GROUPS for the shadow rays of the last light ("Triangle GROUPS" above; any occluder
-// decides the ray there, so the order of the tests is free).  Group records have the form of the
+// Triangle GROUPS for shadow rays ("Triangle GROUPS" above; the order of the tests is free for the
+// last light, and made free for earlier ones by any_accept's lowest-index rule).  Group records
+// have the form of the
 // pre-filter's pair records: the bounding sphere in q' form with R = rgeo + 8u at, the cone axis
 // over kappa' = (smax + b0 + b1 at + 2^-20) * 1.0001, at = rho_max + |C - g|_1 + rext >= |O - v0_t|_1
 // for every member and every ray that starts within rho_max of g (host, rt_capi.cpp commit());
@@ -1565,8 +1566,9 @@ DEVINL int anyhit_sph_pairs_filter(FetchF recf, FetchE rece, int n_rec, int base
 }
 
 // ---------------------------------------------------------------------------------------
-// Sphere GROUPS for shadow rays (rt_device.h SphGroups, last light only: any occluder decides the
-// ray, so the order of the tests is free).  The bounding sphere (C, R) of a group goes through the
+// Sphere GROUPS for shadow rays (rt_device.h SphGroups).  The last light's rays stop at any
+// occluder; earlier lights' rays keep the accepted sphere with the lowest original index
+// (any_accept above): either way the order of the tests is free.  The bounding sphere (C, R) of a group goes through the
 // same q' as a single sphere; R must hold every member's reach.  Member i not rejected at
 // `disc < 0` gives T(w_i) >= -(21.03u |w_i|^2 + u r_i^2 + 2^-149) (above; w_i = O - c_i), i.e. the
 // line's squared distance from c_i is |w_i|^2 - (w_i.L)^2 / |L|^2 <= r_i^2 (1+u) + 29.1u |w_i|^2 + 2^-149

@@ -575,7 +575,7 @@ int commit(esc_context *ctx, const Staged &s) {
     sg_n_grp = n_grp;
     sg_n_sup = n_sup;
   }
-  // ... and the same groups for the last light's shadow rays: pair tables relative to g
+  // ... and the same groups for shadow rays: pair tables relative to g
   std::vector<esc::DevSphPair> sg_sorted2(sg_sorted.size() / 2);
   std::vector<esc::DevSphPairF> sg_sorted2f(sg_sorted.size() / 2), sg_grp2f(sg_grp.size() / 2);
   {

@@ -112,7 +112,7 @@ struct SphGroups {
   DevSphP *sorted_p;         // per frame: DevSphP / DevSphF of `sorted`, DevSphF of `grp`
   DevSphF *sorted_f;
   DevSphF *grp_f;            // n_grp + n_sup + n_hyp
-  // shadow rays of the LAST light (any occluder will do there, rt_device.h sph2_ord): the same
+  // shadow rays (every light; rt_brute.h Any for the lights before the last): the same
   // sorted spheres and groups as pair tables, static per scene.  grp2_f holds the bounding spheres
   // in DevSphPairF form with R = rgeo + 0x1.6p-10 (rho_max + |C - g| + rgeo) (rt_brute.h).
   const DevSphPair *sorted2;    // n_grp * kSphGroup / 2 records
@@ -186,13 +186,15 @@ struct DevLight {
 };
 
 // ---------------------------------------------------------------------------------------
-// Triangle GROUPS (rt_brute.h "Triangle GROUPS"): the sphere groups' two levels for triangles.  The
-// triangles are put in a spatial order (k-d splits over the centroids), cut into groups of 8 and
-// super-groups of 8 groups.  A group record has the form of a triangle's pre-filter record
-// (DevTriPF / DevTriPairPF): the bounding sphere of the members' pre-filter spheres, and -- for the
-// pre-filter's "nearly parallel" escape -- the axis a of a cone that holds every member's normal
-// line, scaled by 1 / kappa with kappa >= sin(cone half-angle) + max tau' / |n1|: a ray nearly
-// parallel to ANY member has |d . a| <= kappa.  Static part per group:
+// Triangle GROUPS (rt_brute.h "Triangle GROUPS"): the sphere groups' three levels for triangles.  The
+// triangles are put in a spatial order (k-d splits over the centroids), cut into groups of 8,
+// super-groups of kTriSuper groups and hyper-groups of kTriHyper super-groups.  A group record has
+// the form of a triangle's pre-filter record (DevTriPF / DevTriPairPF): a bounding sphere that
+// holds every accepted hit point of a member, and -- for the pre-filter's "nearly parallel"
+// escape -- the axis a of a cone of member normals, scaled by 1 / kappa with kappa >= sin(cone
+// half-angle) + max tau' / |n1|: a ray nearly parallel to a member of the cone has |d . a| <= kappa.
+// Shadow rays: the static cone over all members below.  Primary rays: the cone of THIS frame,
+// over the members the camera can take the escape with (DevTriEsc).  Static part per group:
 // ---------------------------------------------------------------------------------------
 constexpr int kTriGroup = 8;
 constexpr int kTriSuper = 16;    // groups per super-group (8: c5 22.9 ms, 16: 19.1, 32: 20.1 at the time)
@@ -224,7 +226,7 @@ struct TriGroups {
   DevTriPF *sorted_pf;
   DevTriPF *grp_pf;              // ... and of the groups / super-groups / hyper-groups
   DevTriEsc *esc;                // per frame: the cone of every node (same indexing as grp)
-  // shadow rays of the last light: static, two per record
+  // shadow rays (every light): static, two per record
   const DevTriPairPF *sorted2_pf;
   const DevTriPairF *sorted2_f;
   const DevTriPairPF *grp2_pf;   // n_grp / 2 records, then n_sup / 2, then n_hyp / 2

@@ -34,7 +34,7 @@ def max_local_rows(H, world, strip_rows=STRIP_ROWS):
     return local_rows(H, 0, world, strip_rows)
 
 
-def gather_to_root(local, rank, world, gathered=None, dst=0, group=None):
+def gather_to_root(local, rank, world, gathered=None, dst=0, group=None, gather_list=None):
     """local: 1-D tensor of max_local_rows*W*C elements (tail rows of short ranks unused).
     gathered (root only): [world, local.numel()] tensor.  Direct peer->root transfers: on xGMI
     every peer has its own link to the root, so 7 peers send concurrently (a ring all-gather
@@ -43,7 +43,10 @@ def gather_to_root(local, rank, world, gathered=None, dst=0, group=None):
         return local.view(1, -1)
     if rank == dst:
         assert gathered is not None and gathered.shape == (world, local.numel())
-        dist.gather(local, gather_list=list(gathered.unbind(0)), dst=dst, group=group)
+        # gather_list: the caller's cached list(gathered.unbind(0)) (a per-frame caller saves the
+        # views' construction; at N = 8 a rank's share of a frame is ~0.1 ms)
+        dist.gather(local, gather_list=gather_list if gather_list is not None
+                    else list(gathered.unbind(0)), dst=dst, group=group)
         return gathered
     dist.gather(local, gather_list=None, dst=dst, group=group)
     return None
