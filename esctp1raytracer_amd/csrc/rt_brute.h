@@ -782,6 +782,17 @@ DEVINL void closest_tri_primary_filter(FetchP recp, FetchF recf, FetchE rece, in
 //   evaluates |h| <= H_t for every member of every group and super-group (tri_escape_possible), and
 //   where no member passes, no ray of the frame can be accepted through (E_t) by any of them:
 //   the record's cone part is switched off.  Only groups with a member seen edge-on keep it.
+//  (K) The two halves trade against each other, level by level.  The pre-filter's proof puts an
+//   accepted hit point within (3 (Du + Dv) + 4u) emax of its triangle with Du + Dv <= (eu + ev +
+//   2.0001 ed) / |det*|; tau_t makes that <= rho_t for |det*| >= tau_t.  For |det*| >= tau_t / k it is
+//   <= 0.9375 k rho_t + 4u emax <= k rho_t (rho_t > 2^-10 emax, k >= 1).  So a level may state
+//   (S_t) with k rho_t (rgeo >= k rho_t + |v - C|) and (E_t), (P) with tau_t / k -- each level
+//   independently, because an accept implies every level's own "(S) or (E)".  Groups use k = 1;
+//   super- and hyper-groups, whose spheres are large anyway, k = kTriSlackSuper / kTriSlackHyper:
+//   their "nearly parallel" bands are k times thinner, H_t shrinks with tau, and a ray outside an
+//   upper level's band and sphere never opens the chain below (c5 k_primary 7.9 -> 4.7 ms).  The
+//   frame's cones come in three chains accordingly (k_prepare_tri_groups / _merge).  Shadow
+//   records keep k = 1: their static cones are dominated by the sine term.
 // A member accept therefore opens its group and super-group; inside an opened group the per-triangle
 // pre-filter, the filter and the reference arithmetic run as before.  Order: as for the sphere
 // groups, an equal closest t goes to the lower ORIGINAL index.

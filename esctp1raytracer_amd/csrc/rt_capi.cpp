@@ -646,6 +646,9 @@ int commit(esc_context *ctx, const Staged &s) {
     std::memset(&pad_g, 0, sizeof(pad_g));
     pad_g.rgeo = -1.f;
     tg_grp.assign(n_grp + n_sup + n_hyp, pad_g);
+    // shadow rays take the plain trade-off (slack 1) at every level: their cones are static, the
+    // sine term dominates them and a thinner tau band buys nothing, while the larger radii cost
+    std::vector<esc::DevTriGroup> tg_grp1(tg_grp.size(), pad_g);
     esc::DevIdx4 pad_i;
     pad_i.v[0] = pad_i.v[1] = pad_i.v[2] = pad_i.v[3] = INT32_MAX / 2;
     tg_orig.assign(n_grp * esc::kTriGroup / 4, pad_i);
@@ -661,11 +664,17 @@ int commit(esc_context *ctx, const Staged &s) {
     for (size_t j = 0; j < n_sup_real; j++) {
       const size_t first = j * kBig;
       tg_grp[n_grp + j] =
+          esc::tri_group_bounds(s.tri, order.data() + first, (int)std::min(kBig, order.size() - first),
+                                esc::kTriSlackSuper);
+      tg_grp1[n_grp + j] =
           esc::tri_group_bounds(s.tri, order.data() + first, (int)std::min(kBig, order.size() - first));
     }
     for (size_t j = 0; j < n_hyp_real; j++) {
       const size_t first = j * kHuge;
       tg_grp[n_grp + n_sup + j] =
+          esc::tri_group_bounds(s.tri, order.data() + first, (int)std::min(kHuge, order.size() - first),
+                                esc::kTriSlackHyper);
+      tg_grp1[n_grp + n_sup + j] =
           esc::tri_group_bounds(s.tri, order.data() + first, (int)std::min(kHuge, order.size() - first));
     }
     tg_n_grp = n_grp;
@@ -673,8 +682,9 @@ int commit(esc_context *ctx, const Staged &s) {
     tg_sorted2f = build_tri2f(tg_sorted);
     tg_sorted2pf = build_tri2pf(tg_sorted);
     tg_grp2pf.resize(tg_grp.size() / 2);
-    for (size_t k = 0; k < tg_grp.size(); k++) {
-      const esc::DevTriGroup &G = tg_grp[k];
+    for (size_t j = 0; j < n_real; j++) tg_grp1[j] = tg_grp[j];
+    for (size_t k = 0; k < tg_grp1.size(); k++) {
+      const esc::DevTriGroup &G = tg_grp1[k];
       esc::DevTriPairPF &F = tg_grp2pf[k >> 1];
       const int h = (int)(k & 1);
       F.cx[h] = F.cy[h] = F.cz[h] = 0.f;
@@ -734,7 +744,7 @@ int commit(esc_context *ctx, const Staged &s) {
     if ((rc = alloc_dev(ctx->tg.sorted_f, tg_sorted.size()))) return rc;
     if ((rc = alloc_dev(ctx->tg.sorted_pf, tg_sorted.size()))) return rc;
     if ((rc = alloc_dev(ctx->tg.grp_pf, tg_grp.size()))) return rc;
-    if ((rc = alloc_dev(ctx->tg.esc, tg_grp.size()))) return rc;
+    if ((rc = alloc_dev(ctx->tg.esc, 3 * tg_grp.size()))) return rc; // three chains (rt_device.h)
     ctx->tg.n_grp = (int32_t)tg_n_grp;
     ctx->tg.n_sup = (int32_t)tg_n_sup;
     ctx->tg.n_hyp = (int32_t)(tg_grp.size() - tg_n_grp - tg_n_sup);

@@ -200,6 +200,11 @@ constexpr int kTriGroup = 8;
 constexpr int kTriSuper = 16;    // groups per super-group (8: c5 22.9 ms, 16: 19.1, 32: 20.1 at the time)
 constexpr int kTriHyper = 8;     // super-groups per hyper-group (the level the sweeps start at)
 constexpr int kTriGroupStep = 4; // hyper-groups per sweep step: n_hyp is a multiple of this
+// The pre-filter's two halves trade against each other: with the escape threshold tau_t / k an
+// accepted hit point lies within k rho_t of its triangle (rt_brute.h).  Upper levels have large
+// bounding spheres anyway and take a large k: their "nearly parallel" bands become k times
+// thinner, and a ray outside them never opens the chain below.
+constexpr float kTriSlackSuper = 8.f, kTriSlackHyper = 32.f; // c5: (2,16) 5.5, (4,32) 4.9, (8,32) 4.7, (16,32) 5.5, (8,64) 5.3 ms
 constexpr int kTriGroupMinTris = 64;
 struct alignas(16) DevTriGroup {
   float cx, cy, cz, rgeo; // rgeo >= rho_t + |v - C| for every vertex v of every member (rho_t: the
@@ -225,7 +230,9 @@ struct TriGroups {
   DevTriF *sorted_f;
   DevTriPF *sorted_pf;
   DevTriPF *grp_pf;              // ... and of the groups / super-groups / hyper-groups
-  DevTriEsc *esc;                // per frame: the cone of every node (same indexing as grp)
+  DevTriEsc *esc;                // per frame: the cones, three chains of n_grp + n_sup + n_hyp nodes
+                                 // (built with k = 1, kTriSlackSuper, kTriSlackHyper; a level's
+                                 // record takes its own chain, whose lower levels feed it)
   // shadow rays (every light): static, two per record
   const DevTriPairPF *sorted2_pf;
   const DevTriPairF *sorted2_f;

@@ -210,7 +210,7 @@ struct TriEscape {
   f3 nh;         // unit normal
   float beta;    // tau / |n1| for this camera
 };
-DEVINL TriEscape tri_escape(const DevTri &T, f3 o) {
+DEVINL TriEscape tri_escape(const DevTri &T, f3 o, float slack_k) {
   TriEscape E;
   E.possible = true;
   E.bounded = false;
@@ -234,7 +234,7 @@ DEVINL TriEscape tri_escape(const DevTri &T, f3 o) {
   const float emax = fmaxf(l1, l2);
   if (!(rho > 0x1.2p-10f * emax) || !(nn > 0.f)) return E; // sliver / no normal
   const float p12 = a1 * a2;
-  const float k = 3.2f * u * emax / rho * 1.0001f;
+  const float k = 3.2f * u * emax / rho * 1.0001f / slack_k; // this level's threshold tau / k
   const float tau = k * ((10.04f * a2 + 5.04f * a1) * at + 20.1f * p12);
   if (!(tau < 0.1f * nn)) return E; // |d . n| < 0.1 is part of the argument
   const float ted = (tau + 10.05f * u * p12) * (1.f + 4.f * u);
@@ -289,60 +289,74 @@ DEVINL DevTriPF tri_group_record(const DevTriGroup &G, f3 o, const DevTriEsc &E)
   return Q;
 }
 
+// the cone of THIS frame over the members [first, first + kTriGroup) that can take the escape at
+// threshold tau / slack_k
+DEVINL DevTriEsc tri_group_cone(const DevTri *sorted, int first, f3 o, float slack_k) {
+  DevTriEsc N;
+  N.ax = N.ay = N.az = N.s = N.beta = 0.f;
+  N.state = 0;
+  f3 acc = mk(0.f, 0.f, 0.f), ref = mk(0.f, 0.f, 0.f);
+  int cnt = 0;
+  for (int m = 0; m < kTriGroup; ++m) {
+    const TriEscape E = tri_escape(sorted[first + m], o, slack_k);
+    if (!E.possible) continue;
+    if (!E.bounded) {
+      N.state = 2;
+      return N;
+    }
+    if (cnt == 0) ref = E.nh;
+    acc = acc + E.nh * ((dot(E.nh, ref) < 0.f) ? -1.f : 1.f);
+    N.beta = fmaxf(N.beta, E.beta);
+    ++cnt;
+  }
+  if (cnt == 0) return N;
+  const float an = sqrtf(dot(acc, acc));
+  if (!(an > 0.5f * (float)cnt)) {
+    N.state = 2; // no useful axis
+    return N;
+  }
+  const f3 ax = acc * (1.f / an);
+  float smax = 0.f;
+  for (int m = 0; m < kTriGroup; ++m) {
+    const TriEscape E = tri_escape(sorted[first + m], o, slack_k);
+    if (!E.possible) continue;
+    const f3 c = cross(ax, E.nh);
+    smax = fmaxf(smax, sqrtf(dot(c, c)));
+  }
+  N.ax = ax.x;
+  N.ay = ax.y;
+  N.az = ax.z;
+  N.s = smax;
+  N.state = 1;
+  return N;
+}
+
 __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, float ox, float oy, float oz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const f3 o = mk(ox, oy, oz);
   if (i < g.n_grp * kTriGroup)
     tri_primary_records(g.sorted[i], o, g.sorted_p[i], g.sorted_f[i], g.sorted_pf[i]);
   if (i < g.n_grp) {
-    DevTriEsc N;
-    N.ax = N.ay = N.az = N.s = N.beta = 0.f;
-    N.state = 0;
-    f3 acc = mk(0.f, 0.f, 0.f), ref = mk(0.f, 0.f, 0.f);
-    int cnt = 0;
-    for (int m = 0; m < kTriGroup; ++m) {
-      const TriEscape E = tri_escape(g.sorted[i * kTriGroup + m], o);
-      if (!E.possible) continue;
-      if (!E.bounded) {
-        N.state = 2;
-        break;
-      }
-      if (cnt == 0) ref = E.nh;
-      acc = acc + E.nh * ((dot(E.nh, ref) < 0.f) ? -1.f : 1.f);
-      N.beta = fmaxf(N.beta, E.beta);
-      ++cnt;
-    }
-    if (N.state != 2 && cnt > 0) {
-      const float an = sqrtf(dot(acc, acc));
-      if (!(an > 0.5f * (float)cnt)) {
-        N.state = 2; // no useful axis
-      } else {
-        const f3 ax = acc * (1.f / an);
-        float smax = 0.f;
-        for (int m = 0; m < kTriGroup; ++m) {
-          const TriEscape E = tri_escape(g.sorted[i * kTriGroup + m], o);
-          if (!E.possible) continue;
-          const f3 c = cross(ax, E.nh);
-          smax = fmaxf(smax, sqrtf(dot(c, c)));
-        }
-        N.ax = ax.x;
-        N.ay = ax.y;
-        N.az = ax.z;
-        N.s = smax;
-        N.state = 1;
-      }
-    }
-    g.esc[i] = N;
-    g.grp_pf[i] = tri_group_record(g.grp[i], o, N);
+    const int n_nodes = g.n_grp + g.n_sup + g.n_hyp;
+    const DevTriEsc N0 = tri_group_cone(g.sorted, i * kTriGroup, o, 1.f);
+    g.esc[i] = N0;                                                                    // chain 0
+    g.esc[n_nodes + i] = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackSuper);   // chain 1
+    g.esc[2 * n_nodes + i] = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackHyper); // chain 2
+    g.grp_pf[i] = tri_group_record(g.grp[i], o, N0);
   }
 }
 
-// level 1 (super-groups from groups) and level 2 (hyper-groups from super-groups)
+// level 1 (super-groups from groups; chains 1 and 2) and level 2 (hyper-groups from super-groups;
+// chain 2): one thread per (node, chain)
 __global__ void __launch_bounds__(256) k_prepare_tri_merge(const TriGroups g, int level, float ox, float oy,
                                                            float oz) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = level == 1 ? g.n_sup : g.n_hyp;
-  if (j >= n) return;
+  const int n_chain = level == 1 ? 2 : 1; // chains that pass through this level
+  if (t >= n * n_chain) return;
+  const int j = t % n, chain = 3 - n_chain + t / n; // level 1: chains 1, 2; level 2: chain 2
+  const int n_nodes = g.n_grp + g.n_sup + g.n_hyp;
+  DevTriEsc *esc = g.esc + (size_t)chain * n_nodes;
   const int fan = level == 1 ? kTriSuper : kTriHyper;
   const int child0 = (level == 1 ? 0 : g.n_grp) + j * fan; // children are consecutive nodes
   const int self = (level == 1 ? g.n_grp : g.n_grp + g.n_sup) + j;
@@ -352,7 +366,7 @@ __global__ void __launch_bounds__(256) k_prepare_tri_merge(const TriGroups g, in
   f3 acc = mk(0.f, 0.f, 0.f), ref = mk(0.f, 0.f, 0.f);
   int cnt = 0;
   for (int c = 0; c < fan; ++c) {
-    const DevTriEsc E = g.esc[child0 + c];
+    const DevTriEsc E = esc[child0 + c];
     if (E.state == 0) continue;
     if (E.state == 2) {
       N.state = 2;
@@ -372,7 +386,7 @@ __global__ void __launch_bounds__(256) k_prepare_tri_merge(const TriGroups g, in
       const f3 ax = acc * (1.f / an);
       float smax = 0.f;
       for (int c = 0; c < fan; ++c) {
-        const DevTriEsc E = g.esc[child0 + c];
+        const DevTriEsc E = esc[child0 + c];
         if (E.state != 1) continue;
         const f3 x = cross(ax, mk(E.ax, E.ay, E.az));
         smax = fmaxf(smax, (sqrtf(dot(x, x)) + E.s) * 1.0001f + 1e-6f);
@@ -384,8 +398,9 @@ __global__ void __launch_bounds__(256) k_prepare_tri_merge(const TriGroups g, in
       N.state = smax < 1.f ? 1 : 2;
     }
   }
-  g.esc[self] = N;
-  g.grp_pf[self] = tri_group_record(g.grp[self], mk(ox, oy, oz), N);
+  esc[self] = N;
+  // the level's own record takes its own chain: super-groups chain 1, hyper-groups chain 2
+  if (chain == level) g.grp_pf[self] = tri_group_record(g.grp[self], mk(ox, oy, oz), N);
 }
 
 // same hoisting for the leaf blocks of the acceleration structure (one thread per block slot)
@@ -1392,7 +1407,7 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
   if (tg->n_grp > 0) {
     hipLaunchKernelGGL(esc::k_prepare_tri_groups, dim3((tg->n_grp * esc::kTriGroup + 255) / 256),
                        dim3(256), 0, stream, *tg, p->origin[0], p->origin[1], p->origin[2]);
-    hipLaunchKernelGGL(esc::k_prepare_tri_merge, dim3((tg->n_sup + 255) / 256), dim3(256), 0, stream,
+    hipLaunchKernelGGL(esc::k_prepare_tri_merge, dim3((2 * tg->n_sup + 255) / 256), dim3(256), 0, stream,
                        *tg, 1, p->origin[0], p->origin[1], p->origin[2]);
     hipLaunchKernelGGL(esc::k_prepare_tri_merge, dim3((tg->n_hyp + 255) / 256), dim3(256), 0, stream,
                        *tg, 2, p->origin[0], p->origin[1], p->origin[2]);

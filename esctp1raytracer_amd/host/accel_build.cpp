@@ -581,10 +581,13 @@ DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, i
 }
 
 // Static record of the triangles order[0 .. count) as one group (rt_device.h DevTriGroup), in
-// double, every bound rounded up.  rgeo >= rho_t + max_v |v - C| over the members' vertices.  Per member: centroid G, bounding radius rho around it, longest
+// double, every bound rounded up.  slack_k >= 1 trades the two halves of the pre-filter against
+// each other for this level (rt_brute.h "Triangle GROUPS"): the escape threshold is tau_t / slack_k,
+// and rgeo >= slack_k rho_t + max_v |v - C| over the members' vertices.  Per member: centroid G, bounding radius rho around it, longest
 // edge emax, n1 = e2 x e1; a member with rho <= 2^-9.9 emax (a sliver: the pre-filter passes those
 // on unconditionally) or without a normal makes the group `always` open.
-DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *order, int count) {
+DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *order, int count,
+                             double slack_k) {
   const double u = 0x1p-24;
   struct M {
     double G[3], rho, nh[3], b0, b1, ext[3], a12, vtx[3][3];
@@ -624,7 +627,8 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
     }
     for (int a = 0; a < 3; a++) m.nh[a] = n1[a] / nn;
     // tau = 3.2u (10.04 |tv||e2| + 5.04 |tv||e1| + 20.1 |e1||e2|) emax / rho (1-norms), rt_brute.h
-    const double k = 3.2 * u * emax / (m.rho / 1.00002) / nn * 1.0001;
+    // ... divided by slack_k for this level: the accepted hit point then lies within slack_k rho
+    const double k = 3.2 * u * emax / (m.rho / 1.00002) / nn * 1.0001 / slack_k;
     m.b1 = k * (10.04 * a2 + 5.04 * a1);
     m.b0 = k * 20.1 * a1 * a2;
     for (int a = 0; a < 3; a++) { // box of the vertices
@@ -666,7 +670,7 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
       const double d[3] = {m.vtx[v][0] - C[0], m.vtx[v][1] - C[1], m.vtx[v][2] - C[2]};
       far_v = std::max(far_v, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
     }
-    rg = std::max(rg, far_v + m.rho);
+    rg = std::max(rg, far_v + slack_k * m.rho);
     rext = std::max(rext, std::fabs(m.ext[0] - C[0]) + std::fabs(m.ext[1] - C[1]) +
                               std::fabs(m.ext[2] - C[2]) + m.a12);
     b0 = std::max(b0, m.b0);
