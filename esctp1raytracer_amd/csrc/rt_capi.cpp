@@ -659,7 +659,10 @@ int commit(esc_context *ctx, const Staged &s) {
     for (size_t j = 0; j < n_real; j++) {
       const size_t first = j * esc::kTriGroup;
       tg_grp[j] = esc::tri_group_bounds(s.tri, order.data() + first,
-                                        (int)std::min((size_t)esc::kTriGroup, order.size() - first));
+                                        (int)std::min((size_t)esc::kTriGroup, order.size() - first),
+                                        esc::kTriSlackGroup);
+      tg_grp1[j] = esc::tri_group_bounds(s.tri, order.data() + first,
+                                         (int)std::min((size_t)esc::kTriGroup, order.size() - first));
     }
     for (size_t j = 0; j < n_sup_real; j++) {
       const size_t first = j * kBig;
@@ -682,7 +685,6 @@ int commit(esc_context *ctx, const Staged &s) {
     tg_sorted2f = build_tri2f(tg_sorted);
     tg_sorted2pf = build_tri2pf(tg_sorted);
     tg_grp2pf.resize(tg_grp.size() / 2);
-    for (size_t j = 0; j < n_real; j++) tg_grp1[j] = tg_grp[j];
     for (size_t k = 0; k < tg_grp1.size(); k++) {
       const esc::DevTriGroup &G = tg_grp1[k];
       esc::DevTriPairPF &F = tg_grp2pf[k >> 1];

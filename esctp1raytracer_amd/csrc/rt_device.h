@@ -204,6 +204,7 @@ constexpr int kTriGroupStep = 4; // hyper-groups per sweep step: n_hyp is a mult
 // accepted hit point lies within k rho_t of its triangle (rt_brute.h).  Upper levels have large
 // bounding spheres anyway and take a large k: their "nearly parallel" bands become k times
 // thinner, and a ray outside them never opens the chain below.
+constexpr float kTriSlackGroup = 1.f; // (2: c5 4.63 instead of 4.73 ms -- not worth a second form in the mirrors)
 constexpr float kTriSlackSuper = 8.f, kTriSlackHyper = 32.f; // c5: (2,16) 5.5, (4,32) 4.9, (8,32) 4.7, (16,32) 5.5, (8,64) 5.3 ms
 constexpr int kTriGroupMinTris = 64;
 struct alignas(16) DevTriGroup {

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, f
     tri_primary_records(g.sorted[i], o, g.sorted_p[i], g.sorted_f[i], g.sorted_pf[i]);
   if (i < g.n_grp) {
     const int n_nodes = g.n_grp + g.n_sup + g.n_hyp;
-    const DevTriEsc N0 = tri_group_cone(g.sorted, i * kTriGroup, o, 1.f);
+    const DevTriEsc N0 = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackGroup);
     g.esc[i] = N0;                                                                    // chain 0
     g.esc[n_nodes + i] = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackSuper);   // chain 1
     g.esc[2 * n_nodes + i] = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackHyper); // chain 2
