@@ -148,6 +148,8 @@ SIGNATURES = {
                                         C.c_int64]),
     "esc_queue_schedule": (C.c_int, [C.c_int32, C.c_int32, _I32, C.c_int32]),
     "esc_tri_group_record": (C.c_int, [_F, C.c_int32, _F]),
+    "esc_sphere_group_record": (C.c_int, [_F, C.c_int32, _F]),
+    "esc_group_order": (C.c_int, [_F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _I32]),
     "esc_last_kernel_ms": (C.c_int, [_P, _F]),
     "esc_reset_counters": (C.c_int, [_P]),
     "esc_read_counters": (C.c_int, [_P, C.POINTER(esc_counters)]),

@@ -1584,6 +1584,35 @@ int esc_tri_group_record(const float *v0e1e2, int32_t count, float record[12]) {
   return ESC_OK;
 }
 
+int esc_sphere_group_record(const float *cxyzr2, int32_t count, float record[4]) {
+  if (!cxyzr2 || !record || count <= 0) {
+    set_error("esc_sphere_group_record: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  std::vector<esc::DevSph> sph((size_t)count);
+  std::vector<int32_t> order((size_t)count);
+  for (int32_t i = 0; i < count; i++) {
+    std::memcpy(&sph[(size_t)i], cxyzr2 + 4 * (size_t)i, 16);
+    order[(size_t)i] = i;
+  }
+  const esc::DevSphGroup g = esc::group_bounds(sph, order.data(), count);
+  std::memcpy(record, &g, 16);
+  return ESC_OK;
+}
+
+int esc_group_order(const float *xyz, int32_t count, int32_t run, int32_t big, int32_t huge,
+                    int32_t *order) {
+  if (!xyz || !order || count <= 0 || run <= 0 || big < run || huge < big || big % run || huge % big) {
+    set_error("esc_group_order: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  std::vector<float> pts(xyz, xyz + 3 * (size_t)count);
+  std::vector<int32_t> o;
+  esc::group_order_points(pts, run, big, huge, o);
+  std::memcpy(order, o.data(), sizeof(int32_t) * (size_t)count);
+  return ESC_OK;
+}
+
 int esc_queue_schedule(int32_t n_triangles, int32_t n_spheres, int32_t *segments,
                        int32_t capacity) {
   if (n_triangles < 0 || n_spheres < 0 || capacity < 0 || (capacity && !segments)) {

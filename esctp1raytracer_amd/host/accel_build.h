@@ -66,6 +66,8 @@ void build_bvh(const std::vector<PrimBox> &boxes, int block, uint32_t key_base, 
 // multiple of the one before) are neighbours, and the bounding sphere of one run.
 void group_order(const std::vector<DevSph> &sph, int run, int big, int huge,
                  std::vector<int32_t> &order);
+void group_order_points(const std::vector<float> &xyz, int run, int big, int huge,
+                        std::vector<int32_t> &order);
 DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, int count);
 // The same for triangles (rt_device.h TriGroups): order over the centroids; a group's static record.
 void group_order(const std::vector<DevTri> &tri, int run, int big, int huge,

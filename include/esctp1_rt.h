@@ -358,6 +358,17 @@ int esc_queue_schedule(int32_t n_triangles, int32_t n_spheres, int32_t *segments
  * floats per triangle (vert0, vert1 - vert0, vert2 - vert0); record receives 12 floats:
  * centre xyz, rgeo, cone axis xyz, smax, rext, b0, b1, always.  Returns 0 or a negative error. */
 int esc_tri_group_record(const float *v0e1e2, int32_t count, float record[12]);
+
+/* The same for spheres (csrc/rt_device.h DevSphGroup): cxyzr2 holds 4 floats per sphere (centre,
+ * r^2); record receives centre xyz and rgeo >= r_i + |c_i - centre| for every sphere. */
+int esc_sphere_group_record(const float *cxyzr2, int32_t count, float record[4]);
+
+/* Host only, for inspection and tests: the spatial order the groups are cut from (k-d median
+ * splits over the points; csrc/rt_device.h SphGroups / TriGroups).  xyz holds 3 floats per point;
+ * order receives a permutation of 0 .. count-1 whose consecutive runs of `run`, `big` and `huge`
+ * points (each a multiple of the one before) are subtrees of the splits. */
+int esc_group_order(const float *xyz, int32_t count, int32_t run, int32_t big, int32_t huge,
+                    int32_t *order);
 /* ms[0] = k_primary, ms[1] = k_shade of the last frame rendered with ESC_RENDER_TIME_KERNELS
  * (waits for that frame).  This is how bench.py prices each kernel against its own roof. */
 int esc_last_kernel_ms(esc_context *ctx, float ms[2]);

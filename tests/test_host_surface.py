@@ -395,3 +395,103 @@ def test_strip_partition_properties(esc):
     check()
     with pytest.raises(esc.EscError):
         esc.strip_local_rows(100, 12, 0, 2)  # strip height must be a multiple of 8
+
+
+# ---------------------------------------------------------------- primitive groups, host side
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 63, 64, 65, 511, 512, 513, 1000, 4097, 20000])
+def test_group_order_is_a_permutation_with_aligned_subtrees(n):
+    """esc_group_order (csrc/rt_device.h SphGroups / TriGroups): the k-d order the groups are cut
+    from.  A permutation; deterministic; and its runs of 8 / 64 / 512 are spatially tighter than
+    runs of the identity order (that is the whole point of sorting)."""
+    import numpy as np
+    from esctp1raytracer_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(n)
+    xyz = np.ascontiguousarray(rng.uniform(-10, 10, (n, 3)), np.float32)
+    order = np.zeros(n, np.int32)
+    FP, IP = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    assert lib.esc_group_order(xyz.ctypes.data_as(FP), n, 8, 64, 512, order.ctypes.data_as(IP)) == 0
+    assert sorted(order.tolist()) == list(range(n))
+    again = np.zeros(n, np.int32)
+    assert lib.esc_group_order(xyz.ctypes.data_as(FP), n, 8, 64, 512, again.ctypes.data_as(IP)) == 0
+    assert (order == again).all()
+    if n >= 512:
+        def spread(idx, run):
+            m = (len(idx) // run) * run
+            p = xyz[idx[:m]].reshape(-1, run, 3)
+            return float((p.max(axis=1) - p.min(axis=1)).max(axis=1).mean())
+        ident = np.arange(n)
+        for run in (8, 64, 512):
+            if 4 * run <= n:
+                assert spread(order, run) < 0.8 * spread(ident, run)
+    # bad arguments are refused
+    assert lib.esc_group_order(xyz.ctypes.data_as(FP), n, 8, 60, 512, order.ctypes.data_as(IP)) < 0
+    assert lib.esc_group_order(xyz.ctypes.data_as(FP), 0, 8, 64, 512, order.ctypes.data_as(IP)) < 0
+
+
+def test_sphere_group_record_holds_every_member():
+    """esc_sphere_group_record: rgeo >= r_i + |c_i - C| for every member, computed against the
+    fp32 centre that is stored, and not wastefully larger than the members' own extent."""
+    import numpy as np
+    from esctp1raytracer_amd import _capi
+    lib = _capi.load()
+    FP = C.POINTER(C.c_float)
+    rng = np.random.default_rng(5)
+    for case in range(300):
+        cnt = int(rng.integers(1, 65))
+        scale = 10.0 ** rng.uniform(-2, 3)
+        off = rng.uniform(-1, 1, 3) * scale * rng.choice([0, 1, 100])
+        c = rng.normal(0, 1, (cnt, 3)) * scale + off
+        r = 10.0 ** rng.uniform(-3, 0, cnt) * scale
+        s = np.ascontiguousarray(np.concatenate([c, (r * r)[:, None]], 1), np.float32)
+        rec = np.zeros(4, np.float32)
+        assert lib.esc_sphere_group_record(s.ctypes.data_as(FP), cnt, rec.ctypes.data_as(FP)) == 0
+        C64 = rec[:3].astype(np.float64)
+        reach = np.sqrt(s[:, 3].astype(np.float64)) + np.linalg.norm(s[:, :3].astype(np.float64) - C64, axis=1)
+        assert (reach <= float(rec[3])).all(), case
+        ext = (s[:, :3].astype(np.float64) + np.sqrt(s[:, 3].astype(np.float64))[:, None]).max(0) - \
+              (s[:, :3].astype(np.float64) - np.sqrt(s[:, 3].astype(np.float64))[:, None]).min(0)
+        assert float(rec[3]) <= 0.87 * np.linalg.norm(ext) * (1 + 1e-5) + 1e-30  # <= half the diagonal
+
+
+def test_triangle_group_record_bounds():
+    """esc_tri_group_record: rgeo >= rho_t + |v - C| over the members' vertices, smax >= the sine
+    between the stored axis and every member's normal line, rext >= |v0 - C|_1 + |e1|_1 + |e2|_1,
+    b0 / b1 > 0; a sliver or a zero-area member makes the group `always` open."""
+    import numpy as np
+    from esctp1raytracer_amd import _capi
+    lib = _capi.load()
+    FP = C.POINTER(C.c_float)
+    rng = np.random.default_rng(9)
+    for case in range(300):
+        cnt = int(rng.integers(1, 129))
+        scale = 10.0 ** rng.uniform(-2, 2)
+        base = rng.normal(0, 1, 3)
+        v0 = rng.normal(0, 1, (cnt, 3)) * scale
+        e1 = (rng.normal(0, 1, (cnt, 3)) * 0.2 + np.cross(base, [1, 0.3, 0.2])) * scale * 0.1
+        e2 = (rng.normal(0, 1, (cnt, 3)) * 0.2 + np.cross(base, [0.1, 1, 0.4])) * scale * 0.1
+        t = np.ascontiguousarray(np.concatenate([v0, e1, e2], 1), np.float32)
+        rec = np.zeros(12, np.float32)
+        assert lib.esc_tri_group_record(t.ctypes.data_as(FP), cnt, rec.ctypes.data_as(FP)) == 0
+        assert rec[11] == 0
+        t64 = t.astype(np.float64)
+        V0, E1, E2 = t64[:, 0:3], t64[:, 3:6], t64[:, 6:9]
+        Cc = rec[:3].astype(np.float64)
+        G = V0 + (E1 + E2) / 3
+        rho = np.sqrt(np.maximum(((G - V0) ** 2).sum(1), np.maximum(((G - V0 - E1) ** 2).sum(1),
+                                                                   ((G - V0 - E2) ** 2).sum(1))))
+        for V in (V0, V0 + E1, V0 + E2):
+            assert (np.linalg.norm(V - Cc, axis=1) + rho <= float(rec[3])).all(), case
+        nrm = np.cross(E2, E1)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        a = rec[4:7].astype(np.float64)
+        sines = np.linalg.norm(np.cross(a / np.linalg.norm(a), nrm), axis=1)
+        assert (sines <= float(rec[7])).all(), case
+        ext = np.abs(V0 - Cc).sum(1) + np.abs(E1).sum(1) + np.abs(E2).sum(1)
+        assert (ext <= float(rec[8])).all(), case
+        assert rec[9] > 0 and rec[10] > 0
+    # a collinear member: always open
+    t = np.ascontiguousarray([[0, 0, 0, 1, 0, 0, 0, 1, 0], [5, 5, 5, 1, 1, 1, 2, 2, 2]], np.float32)
+    rec = np.zeros(12, np.float32)
+    assert lib.esc_tri_group_record(t.ctypes.data_as(FP), 2, rec.ctypes.data_as(FP)) == 0
+    assert rec[11] != 0
