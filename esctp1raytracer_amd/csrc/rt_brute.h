@@ -788,10 +788,12 @@ DEVINL void closest_tri_primary_filter(FetchP recp, FetchF recf, FetchE rece, in
 //   <= 0.9375 k rho_t + 4u emax <= k rho_t (rho_t > 2^-10 emax, k >= 1).  So a level may state
 //   (S_t) with k rho_t (rgeo >= k rho_t + |v - C|) and (E_t), (P) with tau_t / k -- each level
 //   independently, because an accept implies every level's own "(S) or (E)".  Groups use k = 1;
-//   super- and hyper-groups, whose spheres are large anyway, k = kTriSlackSuper / kTriSlackHyper:
-//   their "nearly parallel" bands are k times thinner, H_t shrinks with tau, and a ray outside an
+//   a super- or hyper-group, whose sphere is large anyway, takes the k that doubles its tight
+//   radius (k rho_max <= max |v - C|; host, tri_group_bounds), at most kTriSlackSuper / kTriSlackHyper:
+//   its "nearly parallel" band is k times thinner, H_t shrinks with tau, and a ray outside an
 //   upper level's band and sphere never opens the chain below (c5 k_primary 7.9 -> 4.7 ms).  The
-//   frame's cones come in three chains accordingly (k_prepare_tri_groups / _merge).  Shadow
+//   frame's cones come in three chains accordingly: a group's members are evaluated at k = 1, at
+//   its super-group's k and at its hyper-group's k (k_prepare_tri_groups / _merge).  Shadow
 //   records keep k = 1: their static cones are dominated by the sine term.
 // A member accept therefore opens its group and super-group; inside an opened group the per-triangle
 // pre-filter, the filter and the reference arithmetic run as before.  Order: as for the sphere

@@ -645,6 +645,7 @@ int commit(esc_context *ctx, const Staged &s) {
     esc::DevTriGroup pad_g;
     std::memset(&pad_g, 0, sizeof(pad_g));
     pad_g.rgeo = -1.f;
+    pad_g.slack = 1.f;
     tg_grp.assign(n_grp + n_sup + n_hyp, pad_g);
     // shadow rays take the plain trade-off (slack 1) at every level: their cones are static, the
     // sine term dominates them and a thinner tau band buys nothing, while the larger radii cost
@@ -1579,8 +1580,8 @@ int esc_tri_group_record(const float *v0e1e2, int32_t count, float record[12]) {
     order[(size_t)i] = i;
   }
   const esc::DevTriGroup g = esc::tri_group_bounds(tri, order.data(), count);
-  static_assert(sizeof(g) == 48, "12 floats");
-  std::memcpy(record, &g, sizeof(g));
+  static_assert(offsetof(esc::DevTriGroup, slack) == 48, "the 12 floats of the record come first");
+  std::memcpy(record, &g, 48);
   return ESC_OK;
 }
 

@@ -203,7 +203,8 @@ constexpr int kTriGroupStep = 4; // hyper-groups per sweep step: n_hyp is a mult
 // The pre-filter's two halves trade against each other: with the escape threshold tau_t / k an
 // accepted hit point lies within k rho_t of its triangle (rt_brute.h).  Upper levels have large
 // bounding spheres anyway and take a large k: their "nearly parallel" bands become k times
-// thinner, and a ray outside them never opens the chain below.
+// thinner, and a ray outside them never opens the chain below.  k is chosen per node (host,
+// tri_group_bounds): what doubles the node's tight radius, at most the caps below.
 constexpr float kTriSlackGroup = 1.f; // (2: c5 4.63 instead of 4.73 ms -- not worth a second form in the mirrors)
 constexpr float kTriSlackSuper = 8.f, kTriSlackHyper = 32.f; // c5: (2,16) 5.5, (4,32) 4.9, (8,32) 4.7, (16,32) 5.5, (8,64) 5.3 ms
 constexpr int kTriGroupMinTris = 64;
@@ -214,6 +215,8 @@ struct alignas(16) DevTriGroup {
   float rext;             // >= |v0_t - C|_1 + |e1_t|_1 + |e2_t|_1 for every member
   float b0, b1;           // tau_t / |n1_t| <= b0 + b1 |tvec_t|_1 for every member (rt_brute.h)
   float always;           // != 0: always open (a sliver among the members, or no useful cone)
+  float slack;            // the node's k of statement (K): rgeo, b0, b1 are built with tau / k, k rho
+  float pad[3];
 };
 // the frame's cone of one node (k_prepare_tri_groups / k_prepare_tri_merge): state 0 = no member
 // below can take the escape, 1 = those that can have |d . a| <= beta + |d| s, 2 = nothing can be said

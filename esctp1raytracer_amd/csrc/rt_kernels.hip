@@ -340,8 +340,11 @@ __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, f
     const int n_nodes = g.n_grp + g.n_sup + g.n_hyp;
     const DevTriEsc N0 = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackGroup);
     g.esc[i] = N0;                                                                    // chain 0
-    g.esc[n_nodes + i] = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackSuper);   // chain 1
-    g.esc[2 * n_nodes + i] = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackHyper); // chain 2
+    // chains 1 and 2 at the slack factors of this group's super- and hyper-group
+    const float k_sup = g.grp[g.n_grp + i / kTriSuper].slack;
+    const float k_hyp = g.grp[g.n_grp + g.n_sup + i / (kTriSuper * kTriHyper)].slack;
+    g.esc[n_nodes + i] = tri_group_cone(g.sorted, i * kTriGroup, o, k_sup);
+    g.esc[2 * n_nodes + i] = tri_group_cone(g.sorted, i * kTriGroup, o, k_hyp);
     g.grp_pf[i] = tri_group_record(g.grp[i], o, N0);
   }
 }

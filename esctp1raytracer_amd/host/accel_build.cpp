@@ -581,13 +581,13 @@ DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, i
 }
 
 // Static record of the triangles order[0 .. count) as one group (rt_device.h DevTriGroup), in
-// double, every bound rounded up.  slack_k >= 1 trades the two halves of the pre-filter against
-// each other for this level (rt_brute.h "Triangle GROUPS"): the escape threshold is tau_t / slack_k,
-// and rgeo >= slack_k rho_t + max_v |v - C| over the members' vertices.  Per member: centroid G, bounding radius rho around it, longest
+// double, every bound rounded up.  The node's slack factor k in [1, slack_cap] trades the two
+// halves of the pre-filter against each other (rt_brute.h "Triangle GROUPS", (K)): the escape
+// threshold is tau_t / k, and rgeo >= k rho_t + max_v |v - C| over the members' vertices.  Per member: centroid G, bounding radius rho around it, longest
 // edge emax, n1 = e2 x e1; a member with rho <= 2^-9.9 emax (a sliver: the pre-filter passes those
 // on unconditionally) or without a normal makes the group `always` open.
 DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *order, int count,
-                             double slack_k) {
+                             double slack_cap) {
   const double u = 0x1p-24;
   struct M {
     double G[3], rho, nh[3], b0, b1, ext[3], a12, vtx[3][3];
@@ -627,8 +627,8 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
     }
     for (int a = 0; a < 3; a++) m.nh[a] = n1[a] / nn;
     // tau = 3.2u (10.04 |tv||e2| + 5.04 |tv||e1| + 20.1 |e1||e2|) emax / rho (1-norms), rt_brute.h
-    // ... divided by slack_k for this level: the accepted hit point then lies within slack_k rho
-    const double k = 3.2 * u * emax / (m.rho / 1.00002) / nn * 1.0001 / slack_k;
+    // (divided by this node's slack factor below)
+    const double k = 3.2 * u * emax / (m.rho / 1.00002) / nn * 1.0001;
     m.b1 = k * (10.04 * a2 + 5.04 * a1);
     m.b0 = k * 20.1 * a1 * a2;
     for (int a = 0; a < 3; a++) { // box of the vertices
@@ -644,6 +644,7 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
   std::memset(&g, 0, sizeof(g));
   g.always = 1.f;
   g.rgeo = 0.f;
+  g.slack = 1.f;
   if (always || count == 0) { // the sweeps open it whatever the ray: the other fields are unused
     if (count > 0) {
       g.cx = tri[(size_t)order[0]].v0[0];
@@ -662,6 +663,21 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
   g.cz = (float)(0.5 * (lo[2] + hi[2]));
   const double C[3] = {g.cx, g.cy, g.cz};
   double rg = 0, rext = 0, b0 = 0, b1 = 0, ax[3] = {0, 0, 0};
+  // this node's slack factor k (statement (K)): up to slack_cap, and no larger than what doubles
+  // the node's tight radius -- k rho_max <= max_v |v - C|
+  double slack_k = 1.0;
+  if (slack_cap > 1.0) {
+    double tight = 0, rho_max = 0;
+    for (const M &m : ms) {
+      rho_max = std::max(rho_max, m.rho);
+      for (int v = 0; v < 3; v++) {
+        const double d[3] = {m.vtx[v][0] - C[0], m.vtx[v][1] - C[1], m.vtx[v][2] - C[2]};
+        tight = std::max(tight, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+      }
+    }
+    slack_k = std::min(slack_cap, std::max(1.0, tight / rho_max));
+    slack_k = (double)(float)slack_k; // as stored
+  }
   for (const M &m : ms) {
     // (S_t): the accepted hit point lies within rho_t of the triangle, hence -- the triangle being
     // the convex hull of its vertices -- within rho_t + max_v |v - C| of C
@@ -673,8 +689,8 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
     rg = std::max(rg, far_v + slack_k * m.rho);
     rext = std::max(rext, std::fabs(m.ext[0] - C[0]) + std::fabs(m.ext[1] - C[1]) +
                               std::fabs(m.ext[2] - C[2]) + m.a12);
-    b0 = std::max(b0, m.b0);
-    b1 = std::max(b1, m.b1);
+    b0 = std::max(b0, m.b0 / slack_k);
+    b1 = std::max(b1, m.b1 / slack_k);
     const double sgn = (m.nh[0] * ms[0].nh[0] + m.nh[1] * ms[0].nh[1] + m.nh[2] * ms[0].nh[2]) < 0 ? -1.0 : 1.0;
     for (int a = 0; a < 3; a++) ax[a] += sgn * m.nh[a];
   }
@@ -698,6 +714,7 @@ DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *orde
   g.rext = up(rext * (1.0 + 1e-6));
   g.b0 = up(b0);
   g.b1 = up(b1);
+  g.slack = (float)slack_k;
   g.always = 0.f;
   return g;
 }

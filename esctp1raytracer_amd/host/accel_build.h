@@ -73,6 +73,6 @@ DevSphGroup group_bounds(const std::vector<DevSph> &sph, const int32_t *order, i
 void group_order(const std::vector<DevTri> &tri, int run, int big, int huge,
                  std::vector<int32_t> &order);
 DevTriGroup tri_group_bounds(const std::vector<DevTri> &tri, const int32_t *order, int count,
-                             double slack_k = 1.0);
+                             double slack_cap = 1.0);
 
 } // namespace esc
