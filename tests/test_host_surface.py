@@ -495,3 +495,18 @@ def test_triangle_group_record_bounds():
     rec = np.zeros(12, np.float32)
     assert lib.esc_tri_group_record(t.ctypes.data_as(FP), 2, rec.ctypes.data_as(FP)) == 0
     assert rec[11] != 0
+
+
+def test_committed_profile_was_measured_on_these_sources():
+    """profiles/current.json feeds bench.py's roofline.traffic and `kernels` view; bench.py drops
+    it (traffic: null) when its stamp -- sha256 over csrc/* and the Makefile -- is not the tree's.
+    The committed state must not be in that condition."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    ns = {"os": os, "ROOT": root}
+    exec(src[src.index("def source_stamp():"):src.index("def committed_profile")], ns)
+    cur = json.load(open(os.path.join(root, "profiles", "current.json")))
+    assert cur["source_stamp"] == ns["source_stamp"](), \
+        "csrc/ or the Makefile changed after the last tools/profile.sh + summarize_prof.py --current run"
+    assert cur["hbm_bytes_per_frame"] > 0 and set(cur["valu_insts_per_frame"]) == {"k_primary", "k_shade"}
