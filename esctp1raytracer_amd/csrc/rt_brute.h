@@ -478,6 +478,18 @@ DEVINL void test_sph_primary_sorted(const DevSphP (&s)[4], const DevIdx4 &orig, 
   }
 }
 
+// max / min of the two halves' magnitudes in ONE instruction (|.| source modifiers)
+DEVINL float max_abs2(v2f q) {
+  float t;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%2|" : "=v"(t) : "v"(q.x), "v"(q.y));
+  return t;
+}
+DEVINL float min_abs2(v2f q) {
+  float t;
+  asm("v_min3_f32 %0, |%1|, |%2|, |%2|" : "=v"(t) : "v"(q.x), "v"(q.y));
+  return t;
+}
+
 // the scaled test on 8 records x 2 pixels: wave-uniform mask of the records SOME lane passes
 // (0 for nearly every step: the per-record ballots sit behind one wave-wide check)
 DEVINL uint32_t sph8_primary_mask(const SphF2 (&S)[8], const V3<v2f> &d) {
@@ -492,7 +504,7 @@ DEVINL uint32_t sph8_primary_mask(const SphF2 (&S)[8], const V3<v2f> &d) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const v2f q = j < 4 ? q0[j & 3] : q1[j & 3];
-      if (__builtin_amdgcn_ballot_w64(fmaxf(fabsf(q.x), fabsf(q.y)) >= 1.f) != 0) mask |= 1u << j;
+      if (__builtin_amdgcn_ballot_w64(max_abs2(q) >= 1.f) != 0) mask |= 1u << j;
     }
   }
   return mask;
@@ -882,9 +894,10 @@ DEVINL void closest_tri_primary_groups(FetchP recy, FetchP recu, FetchP recg, Fe
     if (ANY_LANE_RARE(f0 | f1)) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool c = (fmaxf(fabsf(b[j].x), fabsf(b[j].y)) >= 1.f) ||
-                       (fminf(fabsf(g[j].x), fabsf(g[j].y)) <= 1.f);
-        if (__builtin_amdgcn_ballot_w64(c)) mask |= 1u << j;
+        // two ballots OR-ed on the scalar side (a per-lane `||` costs more vector instructions)
+        if ((__builtin_amdgcn_ballot_w64(max_abs2(b[j]) >= 1.f) |
+             __builtin_amdgcn_ballot_w64(min_abs2(g[j]) <= 1.f)) != 0)
+          mask |= 1u << j;
       }
     }
     return mask;
