@@ -1652,21 +1652,27 @@ DEVINL int anyhit_sph_groups_filter(FetchF recy, FetchF recu, FetchF recg, Fetch
       if (__builtin_amdgcn_ballot_w64(m23 >= 0)) exact2(4 * g + 2);
     }
   };
-  // 4 pair records = 8 bounding spheres: wave-uniform mask of the ones some LIVE lane may touch
+  // 4 pair records = 8 bounding spheres: wave-uniform mask of the ones some LIVE lane may touch.
+  // The group tests see the ray through `rg`: its ray-side constant is +inf for a `far` ray (q' =
+  // +inf: every group a candidate) and -inf for a lane that carries no ray (q' = -inf: none), so
+  // the common path has no per-lane case analysis; a ray decided during the sweep may still raise
+  // the flag and is sorted out behind it.
+  RayF rg = rf;
+  rg.o2z_n.y = !(a.tb > 0.f) ? -__builtin_huge_valf() : (far ? __builtin_huge_valf() : rf.o2z_n.y);
   auto open_mask = [&](const PairF(&G)[4]) -> uint32_t {
     v2f q[4];
-    pair4_any_filter_pk(G, rf, q);
-    const bool live = a.tb > 0.f;
+    pair4_any_filter_pk(G, rg, q);
     const int mm = max(max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
                            __float_as_int(q[1].y)),
                        max(max3i(__float_as_int(q[2].x), __float_as_int(q[2].y), __float_as_int(q[3].x)),
                            __float_as_int(q[3].y)));
     uint32_t mask = 0;
-    if (ANY_LANE_RARE(live && (far || mm >= 0))) {
+    if (ANY_LANE_RARE(mm >= 0)) {
+      const bool live = a.tb > 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool c0 = live && (far || __float_as_int(q[j].x) >= 0);
-        const bool c1 = live && (far || __float_as_int(q[j].y) >= 0);
+        const bool c0 = live && __float_as_int(q[j].x) >= 0;
+        const bool c1 = live && __float_as_int(q[j].y) >= 0;
         if (__builtin_amdgcn_ballot_w64(c0)) mask |= 1u << (2 * j);
         if (__builtin_amdgcn_ballot_w64(c1)) mask |= 2u << (2 * j);
         n_open += (int)c0 + (int)c1; // openings THIS ray needs (esc_counters.anyhit_tests)
