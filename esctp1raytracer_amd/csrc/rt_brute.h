@@ -1264,11 +1264,15 @@ DEVINL int anyhit_tri_groups_filter(FetchP recy, FetchP recu, FetchP recg, Fetch
     anyhit_tri_filter(FetchP{recp.p + 4 * g}, FetchF{recf.p + 4 * g}, FetchE{rece.p + 8 * g}, kTriGroup,
                       base + 8 * g, o, L, rs, rf, far, a);
   };
-  // 2 pair records = 4 bounding spheres + cones: wave-uniform mask of the ones a LIVE lane may touch
+  // 2 pair records = 4 bounding spheres + cones: wave-uniform mask of the ones a LIVE lane may touch.
+  // As in the sphere sweep, the group tests see the ray through `rg`: ray-side constant +inf for a
+  // `far` ray (every sphere part a candidate), -inf for a lane without a ray; such a lane can still
+  // raise the flag through the cone part and is sorted out behind it.
+  RayF rg = rs;
+  rg.o2z_n.y = !(a[0].tb > 0.f) ? -__builtin_huge_valf() : (far ? __builtin_huge_valf() : rs.o2z_n.y);
   auto open_mask = [&](const TriPairPF(&R)[2]) -> uint32_t {
     v2f q[2], g[2];
-    tripair2_any_prefilter_pk(R, rs, q, g);
-    const bool live = a[0].tb > 0.f;
+    tripair2_any_prefilter_pk(R, rg, q, g);
     const int mq = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
                        __float_as_int(q[1].y));
     float mn = 2.f;
@@ -1276,11 +1280,12 @@ DEVINL int anyhit_tri_groups_filter(FetchP recy, FetchP recu, FetchP recg, Fetch
         : "+v"(mn)
         : "v"(g[0].x), "v"(g[0].y), "v"(g[1].x), "v"(g[1].y));
     uint32_t mask = 0;
-    if (ANY_LANE_RARE(live && ((mq >= 0) | (mn <= 1.f) | far))) {
+    if (ANY_LANE_RARE((mq >= 0) | (mn <= 1.f))) {
+      const bool live = a[0].tb > 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const bool c0 = live && (far || __float_as_int(q[j].x) >= 0 || fabsf(g[j].x) <= 1.f);
-        const bool c1 = live && (far || __float_as_int(q[j].y) >= 0 || fabsf(g[j].y) <= 1.f);
+        const bool c0 = live && (__float_as_int(q[j].x) >= 0 || fabsf(g[j].x) <= 1.f);
+        const bool c1 = live && (__float_as_int(q[j].y) >= 0 || fabsf(g[j].y) <= 1.f);
         if (__builtin_amdgcn_ballot_w64(c0)) mask |= 1u << (2 * j);
         if (__builtin_amdgcn_ballot_w64(c1)) mask |= 2u << (2 * j);
         n_open += (int)c0 + (int)c1;
