@@ -205,7 +205,7 @@ constexpr int kTriGroupStep = 4; // hyper-groups per sweep step: n_hyp is a mult
 // bounding spheres anyway and take a large k: their "nearly parallel" bands become k times
 // thinner, and a ray outside them never opens the chain below.  k is chosen per node (host,
 // tri_group_bounds): what doubles the node's tight radius, at most the caps below.
-constexpr float kTriSlackGroup = 1.f; // (2: c5 4.63 instead of 4.73 ms -- not worth a second form in the mirrors)
+constexpr float kTriSlackGroup = 1.f; // (per node as for the upper levels: c5 4.32 instead of 4.44 ms -- not worth a second form in the mirrors; 0.25: 5.56)
 constexpr float kTriSlackSuper = 8.f, kTriSlackHyper = 32.f; // c5: (2,16) 5.5, (4,32) 4.9, (8,32) 4.7, (16,32) 5.5, (8,64) 5.3 ms
 constexpr int kTriGroupMinTris = 64;
 struct alignas(16) DevTriGroup {

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) k_prepare_tri_groups(const TriGroups g, f
     tri_primary_records(g.sorted[i], o, g.sorted_p[i], g.sorted_f[i], g.sorted_pf[i]);
   if (i < g.n_grp) {
     const int n_nodes = g.n_grp + g.n_sup + g.n_hyp;
-    const DevTriEsc N0 = tri_group_cone(g.sorted, i * kTriGroup, o, kTriSlackGroup);
+    const DevTriEsc N0 = tri_group_cone(g.sorted, i * kTriGroup, o, g.grp[i].slack); // its own k
     g.esc[i] = N0;                                                                    // chain 0
     // chains 1 and 2 at the slack factors of this group's super- and hyper-group
     const float k_sup = g.grp[g.n_grp + i / kTriSuper].slack;
