@@ -14,8 +14,13 @@ RCCL and laid out as one frame there; total work is fixed, so scaling is "strong
 
 Rank 0 prints ONE JSON line.  `value` = rays of all ranks / wall time (max over ranks) in
 Mrays/s; rays = primary (W*H) + shadow (hit pixels x lights), counted by the kernel itself.
+The timed path sweeps the linear primitive table through three levels of spatial groups
+(bounding spheres / normal cones in front of the same conservative filters: DESIGN.md 3.6-3.7) and
+`config.workload` says so; `linear` is the same frame with every (ray, primitive) pair visited in
+the reference's index order (ESC_RENDER_INDEX_ORDER) -- BASELINE's "brute-force intersect" point.
 `roofline` is the HBM view north_star asks for (algorithmic bytes / measured kernel time vs
-8 TB/s) and `roofline_valu` the view that actually bounds this kernel.
+8 TB/s); `valu` holds what actually bounds these kernels, from the committed rocprofv3 counters
+(VALU busy, wait shares, instructions per wave), for both paths.
 `cpu_baseline` times the test oracle (oracle/rt_oracle.c, a strict-IEEE restatement of the
 reference's scalar path: the reference's ISPC path cannot be built, `ispc` is not in the image)
 on a bounded sample of rows of the SAME frame on all host cores, rank 0 at N=1 only.
@@ -36,8 +41,7 @@ import esctp1raytracer_amd as esc  # noqa: E402
 from esctp1raytracer_amd import multigpu  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec)
-FP32_VALU_PEAK_TF = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
-F_SPHERE, F_TRI = 19, 51   # algorithmic flop per ray-primitive test, SURVEY.md 8(d)
+N_SIMD, N_XCD = 1024, 8   # 256 CUs x 4 SIMDs in 8 XCDs (MI355X_MICROARCH.md)
 
 
 def source_stamp():
@@ -55,28 +59,41 @@ def source_stamp():
 
 
 def committed_profile(config):
-    """profiles/current.json: per-frame PMC numbers of the SHIPPED kernels (tools/summarize_prof.py
-    writes it, stamped with source_stamp()).  Returns None when it belongs to other sources --
-    a stale counter must never be passed off as this run's."""
+    """profiles/current.json: per-frame PMC numbers of the SHIPPED kernels, grouped and linear paths
+    (tools/summarize_prof.py writes it, stamped with source_stamp()).  Returns None when it belongs to
+    other sources -- a stale counter must never be passed off as this run's."""
     path = os.path.join(ROOT, "profiles", "current.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         prof = json.load(f)
-    if prof.get("source_stamp") != source_stamp() or prof.get("config") != config:
+    if prof.get("source_stamp") != source_stamp() or prof.get("config") != config or "paths" not in prof:
         return None
     return prof
 
 
-# Issue cost of one wave64 instruction on one SIMD with several waves resident, in cycles at the
-# nominal 2.4 GHz, measured on this chip: plain VALU and v_pk_mul/add_f32 by tools/ubench/
-# valu_rate.hip; v_pk_fma_f32 with one SGPR-pair operand by tools/ubench/filter_rate.hip (mode 3,
-# the primary filter's loop from registers: 144.9 cycles per 24 v_pk_fma + 9 plain).  A
-# v_pk_fma_f32 with three VGPR-pair operands costs 8.1 -- the filters have none in their loops.
-CYC_PLAIN, CYC_PK, CYC_PK_FMA = 2.66, 4.1, 5.04
-# VALU instruction mix of each hot loop (counted in the ISA, `make asm`): (pk_fma, pk mul/add, plain)
-LOOP_MIX = {"k_primary": (24, 0, 9),   # per 8 spheres x 128 rays
-            "k_shade": (28, 4, 5)}      # per 4 pair records (8 spheres) x 64 rays
+def counter_view(kern):
+    """One kernel class of profiles/current.json -> the numbers that say what bounds it.  SQ counters
+    are summed over the chip; SQ_ACTIVE_INST_VALU and the SQ_WAIT_* / SQ_WAVE_CYCLES counters tick in
+    quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, counter section)."""
+    g = kern.get
+    out = {}
+    if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
+        out["valu_busy"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (N_SIMD * g("GRBM_GUI_ACTIVE") / N_XCD)
+    if g("SQ_WAVE_CYCLES"):
+        if g("SQ_WAIT_ANY") is not None:
+            out["wait_any_share_of_wave_cycles"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+        if g("SQ_WAIT_INST_ANY") is not None:
+            out["wait_inst_any_share_of_wave_cycles"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+    if g("SQ_WAVES"):
+        for c, k in (("SQ_INSTS_VALU", "valu_insts_per_wave"), ("SQ_INSTS_SALU", "salu_insts_per_wave"),
+                     ("SQ_INSTS_SMEM", "smem_insts_per_wave")):
+            if g(c) is not None:
+                out[k] = g(c) / g("SQ_WAVES")
+    for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"):
+        if g(c) is not None:
+            out[c.lower() + "_per_frame"] = g(c)
+    return out
 
 
 def parse():
@@ -91,6 +108,12 @@ def parse():
     ap.add_argument("--stage", default="auto", choices=["auto", "smem", "lds", "bvh"],
                     help="auto/smem/lds are brute force (BASELINE's algorithm, the default); bvh "
                          "makes the opt-in acceleration structure the measured path")
+    ap.add_argument("--path", default="grouped", choices=["grouped", "linear"],
+                    help="grouped (default): the table is swept through its spatial groups; linear: "
+                         "ESC_RENDER_INDEX_ORDER, every pair in the reference's index order, is the "
+                         "TIMED path (what tools/profile.sh wraps for the `linear` counters)")
+    ap.add_argument("--linear-steps", type=int, default=-1,
+                    help="frames of the `linear` leg (default: min(steps, 5); 0 = skip)")
     ap.add_argument("--no-accel", action="store_true",
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
     ap.add_argument("--profile-run", action="store_true",
@@ -277,6 +300,7 @@ def main():
     cam = esc.Camera.for_image(eye, look, W, H)
     stage = {"auto": esc.ESC_STAGE_AUTO, "smem": esc.ESC_STAGE_SMEM, "lds": esc.ESC_STAGE_LDS,
              "bvh": esc.ESC_STAGE_BVH}[a.stage]
+    path_flags = esc.ESC_RENDER_INDEX_ORDER if a.path == "linear" else 0
 
     st = torch.cuda.Stream(device=dev)
     r = esc.Renderer(local_rank, stream=st)
@@ -337,7 +361,7 @@ def main():
             e0.record(ss)
             rr.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
                              out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows,
-                             stage=stage)
+                             stage=stage, flags=path_flags)
             e1.record(ss)
             if timed:
                 events.append((e0, e1))
@@ -390,7 +414,7 @@ def main():
             with torch.cuda.stream(st):
                 r.render_strips(cam, W, H, 0, 1, out_f32=None if use_u8 else local[0],
                                 out_u8=local[0] if use_u8 else None, strip_rows=S, shadows=shadows,
-                                stage=stage, flags=esc.ESC_RENDER_TIME_KERNELS)
+                                stage=stage, flags=esc.ESC_RENDER_TIME_KERNELS | path_flags)
             ms = r.last_kernel_ms()
             acc[0] += ms[0]
             acc[1] += ms[1]
@@ -398,27 +422,53 @@ def main():
                         "note": "k_shade_ms = everything after k_primary: the fused k_shade, or "
                                 "k_shadow_setup + k_anyhit_segment x segments + k_shade_finish"}
 
-    # the reference's any-hit count: one frame in index order (the default sweeps long sphere lists
-    # in another order for the last light and so executes fewer tests; the image is the same)
+    # `linear`: the same frame with every (ray, primitive) pair visited in the reference's index
+    # order (ESC_RENDER_INDEX_ORDER: no groups, no re-ordered last light) -- BASELINE's "brute-force
+    # intersect" point, and the reference's own any-hit count.  A few frames between HIP events on
+    # the render stream, after the timed region; the first one (untimed) allocates the queue form's
+    # scratch.
+    linear = None
     anyhit_index_order = None
-    index_order_ms = None
-    if world == 1 and a.stage != "bvh" and not a.profile_run:
-        r.synchronize()
-        r.reset_counters()
-        ei0, ei1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(4):  # the first such frame allocates the queue form's scratch: best of 4
+    n_lin = a.linear_steps if a.linear_steps >= 0 else min(a.steps, 5)
+    if world == 1 and a.stage != "bvh" and not a.profile_run and a.path == "grouped" and n_lin > 0:
+        lin_ev = []
+        for i in range(n_lin + 1):
             with torch.cuda.stream(st):
-                r.reset_counters()
-                ei0.record(st)
+                if i == 1:
+                    r.reset_counters()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(st)
                 r.render_strips(cam, W, H, 0, 1, out_f32=None if use_u8 else local[0],
                                 out_u8=local[0] if use_u8 else None, strip_rows=S, shadows=shadows,
                                 stage=stage, flags=esc.ESC_RENDER_INDEX_ORDER)
-                ei1.record(st)
-            r.synchronize()
-            ms_i = ei0.elapsed_time(ei1)
-            index_order_ms = ms_i if index_order_ms is None else min(index_order_ms, ms_i)
-        anyhit_index_order = r.counters()["anyhit_tests"]
+                e1.record(st)
+            if i:
+                lin_ev.append((e0, e1))
+        r.synchronize()
+        lc = r.counters()
+        lin_ms = sum(x.elapsed_time(y) for x, y in lin_ev) / len(lin_ev)
+        with torch.cuda.stream(st):
+            r.render_strips(cam, W, H, 0, 1, out_f32=None if use_u8 else local[0],
+                            out_u8=local[0] if use_u8 else None, strip_rows=S, shadows=shadows,
+                            stage=stage, flags=esc.ESC_RENDER_INDEX_ORDER | esc.ESC_RENDER_TIME_KERNELS)
+        lsplit = r.last_kernel_ms()
+        anyhit_index_order = lc["anyhit_tests"] / n_lin
+        linear = {"flag": "ESC_RENDER_INDEX_ORDER", "steps": n_lin, "ms_per_step": lin_ms,
+                  "rays_per_frame": (lc["primary_rays"] + lc["shadow_rays"]) / n_lin,
+                  "value": (lc["primary_rays"] + lc["shadow_rays"]) / n_lin / (lin_ms * 1e-3) / 1e6,
+                  "unit": "Mrays/s",
+                  "anyhit_tests_per_frame": anyhit_index_order,
+                  "shadow_lane_efficiency": (lc["anyhit_tests"] / lc["anyhit_lane_tests"]
+                                             if lc["anyhit_lane_tests"] else None),
+                  "kernel_split": {"k_primary_ms": lsplit[0], "shading_ms": lsplit[1]}}
         r.reset_counters()
+        # the timed path's frame back in local[0] (parity spot-check and the BVH comparison read it)
+        with torch.cuda.stream(st):
+            r.render_strips(cam, W, H, 0, 1, out_f32=None if use_u8 else local[0],
+                            out_u8=local[0] if use_u8 else None, strip_rows=S, shadows=shadows,
+                            stage=stage, flags=path_flags)
+        r.synchronize()
     # one un-pipelined frame: launch -> complete frame resident on rank 0
     fence()
     t1 = time.perf_counter()
@@ -476,13 +526,20 @@ def main():
         gbs = alg_bytes / (roof_ms * 1e-3) / 1e9
         prof = committed_profile(a.config) if (world == 1 and not a.prims and not a.width
                                                and a.stage == "auto") else None
-        traffic = prof["hbm_bytes_per_frame"] if prof else None
-        share = my_rows / H
-        closest_flop = (primary / a.steps) * share * (n_tri * F_TRI + n_sph * F_SPHERE)
-        f_any = (n_tri * F_TRI + n_sph * F_SPHERE) / max(n_tri + n_sph, 1)
-        ref_anyhit = anyhit_index_order if anyhit_index_order is not None else anyhit / a.steps
-        anyhit_flop = ref_anyhit * share * f_any
-        tf = (closest_flop + anyhit_flop) / (roof_ms * 1e-3) / 1e12
+        ppath = prof["paths"].get(a.path) if prof else None
+        traffic = ppath.get("hbm_bytes_per_frame") if ppath else None
+        algorithm = {
+            "bvh": "bounding-volume tree + screen / light bins (ESC_STAGE_BVH, opt-in)",
+            "linear": "linear sweep of the primitive table in the reference's index order "
+                      "(ESC_RENDER_INDEX_ORDER): every (ray, primitive) pair is decided by the "
+                      "reference arithmetic or by a proven conservative filter in front of it -- "
+                      "BASELINE's brute-force intersect",
+            "grouped": ("3-level group culling over the linear primitive table: the proven filters "
+                        "run on bounding spheres / normal cones of spatial groups of 8, 64-128 and "
+                        "512-1,024 primitives first, members of opened groups go through the same "
+                        "filters and the reference arithmetic (DESIGN.md 3.6-3.7); tables under 64 "
+                        "primitives are swept linearly"),
+        }["bvh" if a.stage == "bvh" else a.path]
         out = {
             "metric": "Mrays/sec + frame ms, 3840x2160 / 10k spheres, at 1/2/4/8 MI355X",
             "value": rays / elapsed / 1e6,
@@ -500,14 +557,9 @@ def main():
             "config": {
                 "workload": f"{a.config}: {W}x{H}, {n_sph} spheres + {n_tri} triangles, "
                             f"{info['n_lights']} light, 1 primary ray/pixel + "
-                            f"{'1 shadow ray per hit pixel' if shadows else 'no shadow rays'}, "
-                            f"{'bounding-volume tree (opt-in)' if a.stage == 'bvh' else 'brute force'}",
-                "sweep": ("every (ray, primitive) pair is decided by the reference arithmetic or by a proven "
-                          "conservative filter; from 64 primitives up the filters run on bounding spheres / "
-                          "normal cones of spatial groups of 8, 64-128 and 512-1,024 primitives first "
-                          "(DESIGN.md 3.6-3.7).  index_order_frame_ms = the same frame swept linearly in the "
-                          "reference's index order (ESC_RENDER_INDEX_ORDER), best of four such frames, same run"),
-                "index_order_frame_ms": index_order_ms,
+                            f"{'1 shadow ray per hit pixel' if shadows else 'no shadow rays'}; "
+                            f"{algorithm}",
+                "path": "bvh" if a.stage == "bvh" else a.path,
                 "scene": "esc_scene_synthetic (SURVEY.md 8(d)): splitmix64 seeds 0xC2..0xC4",
                 "partition": f"{S}-row strips round-robin over {world} rank(s)",
                 "gather": ("none (1 GPU)" if world == 1 else
@@ -520,14 +572,14 @@ def main():
                 "primary_rays_per_frame": primary / a.steps,
                 "shadow_rays_per_frame": shadow / a.steps,
                 "hit_pixels_per_frame": hits / a.steps,
-                "closest_hit_tests_per_frame": primary / a.steps * (n_tri + n_sph),
+                "pairs_per_frame_closest_hit": primary / a.steps * (n_tri + n_sph),
                 "anyhit_tests_per_frame": anyhit / a.steps,
                 "anyhit_tests_per_frame_index_order": anyhit_index_order,
                 "shadow_lane_efficiency": (anyhit / lane_tests) if lane_tests else None,
             },
-            "kernel": {"name": "one frame = k_primary + the shading kernels (fused k_shade for short "
-                               "primitive lists; k_shadow_setup + k_anyhit_segment per segment + "
-                               "k_shade_finish per light otherwise), back to back on one stream"
+            "kernel": {"name": "one frame = k_primary + the shading kernels (fused k_shade; or, for "
+                               "long linearly swept lists, k_shadow_setup + k_anyhit_segment per "
+                               "segment + k_shade_finish per light), back to back on one stream"
                                + ("" if world == 1 else "; N>1: two frames are in flight on two "
                                   "streams, so this duration includes time shared with the other frame"),
                        "avg_ms": kernel_ms,
@@ -535,48 +587,38 @@ def main():
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "traffic_source": (prof["source"] if prof else
+                         "traffic_source": (prof["source"] if ppath else
                                             "null: profiles/current.json is missing or was "
                                             "measured on other sources (stamp mismatch)"),
                          "traffic_note": "algorithmic = fp32 framebuffer + scene tables (SURVEY.md "
-                                         "8(d)); measured traffic (rocprofv3 --pmc FETCH_SIZE / "
-                                         "WRITE_SIZE passes, fetch doubled per the gfx950 note) also "
-                                         "holds the hit planes k_primary hands over and the shadow-ray "
-                                         "queue; the kernels are VALU-bound, see roofline_valu"},
-            "roofline_valu": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TF,
-                              "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
-                              "note": "algorithmic flop (19/sphere test, 51/triangle test) of the "
-                                      "tests the REFERENCE executes / kernel time.  Not an "
-                                      "executed-op rate: the kernels hoist per-primitive work and "
-                                      "run a 4- / 8-op FMA filter instead of the 7- / 16-op test for "
-                                      "all but the candidate pairs, so this can exceed 1; the "
-                                      "executed view is `kernels`"},
+                                         "8(d)); measured traffic = rocprofv3 --pmc FETCH_SIZE / "
+                                         "WRITE_SIZE passes, fetch doubled per the gfx950 note; the "
+                                         "kernels are VALU-bound, not HBM-bound: see `valu`"},
         }
         if kernel_split is not None:
             out["kernel_split"] = kernel_split
-            # executed-instruction view per kernel: VALU wave-instructions (committed rocprofv3
-            # SQ_INSTS_VALU, stamped) x measured issue cost / (kernel time x SIMDs x clock)
-            ks = {}
-            for name, ms_key in (("k_primary", "k_primary_ms"), ("k_shade", "k_shade_ms")):
-                ent = {"ms": kernel_split[ms_key]}
-                if prof and name in prof.get("valu_insts_per_frame", {}):
-                    insts = prof["valu_insts_per_frame"][name]
-                    nf, npk, npl = LOOP_MIX[name]
-                    cyc = (nf * CYC_PK_FMA + npk * CYC_PK + npl * CYC_PLAIN) / (nf + npk + npl)
-                    clock_ghz = prof.get("clock_ghz", 2.4)
-                    avail = ent["ms"] * 1e-3 * clock_ghz * 1e9 * 1024  # SIMD-cycles
-                    # executed VALU instructions per SIMD-cycle against what the pipe can issue:
-                    # between 1 / 5.04 (nothing but v_pk_fma_f32) and 1 / 2.66 (nothing but plain
-                    # VALU); `issue_frac` prices every instruction at the filter bodies' mix and
-                    # can exceed 1 where the sweeps' bookkeeping (cheaper plain VALU) dominates
-                    ent.update({"valu_insts": insts, "clock_ghz": clock_ghz,
-                                "valu_insts_per_simd_cycle": insts / avail,
-                                "issue_ceiling_per_simd_cycle": [1 / CYC_PK_FMA, 1 / CYC_PLAIN],
-                                "filter_body_mix_pkfma_pk_plain": [nf, npk, npl],
-                                "cycles_per_inst_at_body_mix": cyc,
-                                "issue_frac": insts * cyc / avail})
-                ks[name] = ent
-            out["kernels"] = ks
+        # what bounds the kernels: committed rocprofv3 counters of the shipped sources (stamped)
+        if prof:
+            valu = {"source": prof["source"] + " (rocprofv3 --pmc, source-stamped; tools/profile.sh)",
+                    "definitions": "valu_busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / "
+                                   "8 XCDs); wait shares = SQ_WAIT_ANY, SQ_WAIT_INST_ANY / "
+                                   "SQ_WAVE_CYCLES; instructions are wave instructions"}
+            for pname, pp in prof["paths"].items():
+                valu[pname] = {k: counter_view(v) for k, v in pp.get("kernels", {}).items()}
+            out["valu"] = valu
+        if linear is not None:
+            lin_bytes = alg_bytes
+            linear["roofline"] = {"bound": "hbm", "achieved": lin_bytes / (linear["ms_per_step"] * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": lin_bytes / (linear["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": (prof["paths"]["linear"].get("hbm_bytes_per_frame")
+                                              if prof and "linear" in prof["paths"] else None)}
+            linear["pairs_per_second"] = ((primary / a.steps * (n_tri + n_sph) + anyhit_index_order)
+                                          / (linear["ms_per_step"] * 1e-3))
+            linear["note"] = ("the same frame, every (ray, primitive) pair in the reference's index "
+                              "order through the filters + the reference arithmetic: no groups, no "
+                              "re-ordered last light; the brute-force point BASELINE config 5 names")
+            out["linear"] = linear
         if pipelined is not None:
             pipelined["value"] = rays / a.steps / (pipelined["ms_per_step"] * 1e-3) / 1e6
             out["pipelined"] = pipelined
@@ -586,7 +628,10 @@ def main():
                 gpu_frame = local[0][:H * W * 3].cpu().numpy().reshape(H, W, 3)
             cb, same = cpu_baseline(scene, eye, look, W, H, shadows, a.cpu_rows, gpu_frame)
             out["cpu_baseline"] = cb
-            out["gpu_vs_cpu"] = out["value"] / cb["value"]
+            # like for like: the CPU baseline sweeps every pair linearly, as `linear` does
+            out["gpu_vs_cpu"] = {
+                "linear_over_cpu": (linear["value"] / cb["value"]) if linear else None,
+                ("bvh" if a.stage == "bvh" else a.path) + "_over_cpu": out["value"] / cb["value"]}
             out["parity_sample_rows_bit_exact"] = same
         if world == 1 and a.stage != "bvh" and not a.no_accel and not use_u8:
             out["accel"] = accel_leg(esc, r, st, cam, eye, look, W, H, shadows, a.steps, a.warmup,

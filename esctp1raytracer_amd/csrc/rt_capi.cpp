@@ -148,6 +148,7 @@ esc::DevMat dev_material(const esc::Material &m, bool has_normals) {
   std::memcpy(d.ke, m.ke, 12);
   d.Ns = m.Ns;
   d.has_normals = has_normals ? 1 : 0;
+  d.spec_free = esc::material_spec_free(d.ks, d.Ns);
   return d;
 }
 
@@ -252,6 +253,7 @@ int stage_flat(int32_t nt, const ispc_triangle *tris, int32_t nl, const ispc_lig
     std::memcpy(m.ke, t.ke, 12);
     m.Ns = t.Ns;
     m.has_normals = t.has_normals ? 1 : 0;
+    m.spec_free = esc::material_spec_free(m.ks, m.Ns);
     if (any_normals) {
       esc::DevTriN n;
       std::memset(&n, 0, sizeof(n));

@@ -167,8 +167,18 @@ struct alignas(16) DevMat {
   float ke[3];
   float Ns;
   int32_t has_normals;
-  int32_t pad[2];
+  int32_t spec_free; // material_spec_free(ks, Ns): the specular term is +-0 whatever powf returns
+  int32_t pad;
 };
+// main.cpp:782-783 adds ks * pow(dot(N, H), Ns) to the diffuse term.  With ks == (+-0, +-0, +-0) the
+// product is +-0 with the sign of ks -- i.e. ks itself, bit for bit -- as soon as the power is a
+// finite value >= +0 (not NaN, not -0, not inf).  rt_kernels.hip phong() establishes at run time
+// that its base lies in [0.49, 1.001] (unit N and L, dot(N, L) > 0); for such a base and an exponent in
+// [0, 1024] the power lies in [+0, 2.8] (it may underflow to +0, never to -0): the skip is value-
+// preserving exactly for the materials flagged here.  NaN / negative / huge Ns are not flagged.
+inline int32_t material_spec_free(const float ks[3], float Ns) {
+  return (ks[0] == 0.f && ks[1] == 0.f && ks[2] == 0.f && Ns >= 0.f && Ns <= 1024.f) ? 1 : 0;
+}
 
 // per-triangle vertex normals, only read at shading (main.cpp:734-737)
 struct DevTriN {

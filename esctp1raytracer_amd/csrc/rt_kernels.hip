@@ -600,6 +600,39 @@ DEVINL f3 primary_dir(const RenderParams &p, int w, int h) {
   return normalize(((ld3(p.llc) + ld3(p.horizontal) * is) + ld3(p.vertical) * it) - origin);
 }
 
+// main.cpp:768-788 for one light whose shadow ray found no occluder: this light's Phong term added
+// to (r, g, b).  nl = the number of lights as a float.
+// The specular term ks * pow(dot(N, H), Ns) costs a normalise and a powf; it is skipped (a branch the
+// whole wave takes together on the BASELINE scenes) where it is +-0 whatever the power is: the
+// material is flagged spec_free (rt_device.h material_spec_free: ks == +-0, Ns in [0, 1024]) AND the
+// power is certain to be finite and >= +0.  That holds when |N|^2 and |L|^2, evaluated right here, lie in
+// [0.999, 1.001]: both are then finite, d = fl-dot(N, L) > 0 is not a NaN and the real N.L >= -10u, so
+// S = N + L has |S|^2 >= 1.99, 2S normalises without underflow or overflow to a unit H, and
+// x = fl-dot(N, H) lies within 12u of (|N|^2 + N.L) / |S|, in [0.49, 1.001]; powf of such a base to
+// an exponent in [0, 1024] is a finite value in [+0, 2.8].  ks * that is ks itself, bit for bit
+// (+-0 times a finite non-negative value keeps the sign of the zero), which is what `sp = 1` gives.
+DEVINL void phong_add(const DevMat &M, f3 N, f3 rL, float nl, float &r, float &g, float &b) {
+  const float d = dot(N, rL); // :775
+  if (!(d <= 0.f)) {          // :777
+    // x / 1.0f == x bit for bit, so a single light skips the six correctly rounded divides
+    f3 c = ld3(M.ka) * 0.5f + ld3(M.ke); // :769-770
+    if (nl != 1.f) c = c / nl;
+    const float nn = dot(N, N), ll = dot(rL, rL);
+    const bool skip = M.spec_free != 0 && nn >= 0.999f && nn <= 1.001f && ll >= 0.999f && ll <= 1.001f;
+    float sp = 1.f;
+    if (!skip) {
+      const f3 Hh = normalize((N + rL) * 2.f); // :780
+      sp = powf(dot(N, Hh), M.Ns);
+    }
+    f3 ds = ld3(M.kd) * d + ld3(M.ks) * sp; // :782-783
+    if (nl != 1.f) ds = ds / nl;
+    c = c + ds;
+    r += c.x; // :786-788
+    g += c.y;
+    b += c.z;
+  }
+}
+
 // This thread's tile position, RECOMPUTED from the thread id through an opaque copy: used by
 // k_shade<SMEM> inside and after the light loop, so that pixel coordinates and tile fields do not
 // occupy VGPRs across the any-hit sweeps (they cost 36 B of scratch per lane there otherwise).
@@ -1069,21 +1102,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
       if (p.shadows && a[0].kocc >= 0) {
         t = a[0].tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
       } else {         // :772-773 `continue` otherwise
-        const float d = dot(N, rL); // :775
-        if (!(d <= 0.f)) {          // :777
-          const DevMat M = p.mat[mi];                  // :768
-          // x / 1.0f == x bit for bit, so a single light skips the six correctly rounded divides
-          f3 c = ld3(M.ka) * 0.5f + ld3(M.ke);         // :769-770
-          if (nl != 1.f) c = c / nl;
-          const f3 Hh = normalize((N + rL) * 2.f);     // :780
-          const float sp = powf(dot(N, Hh), M.Ns);
-          f3 ds = ld3(M.kd) * d + ld3(M.ks) * sp;      // :782-783
-          if (nl != 1.f) ds = ds / nl;
-          c = c + ds;
-          r += c.x;                                       // :786-788
-          g += c.y;
-          b += c.z;
-        }
+        phong_add(p.mat[mi], N, rL, nl, r, g, b); // :768-788
       }
     }
     if constexpr (STAGE == STAGE_SMEM) {
@@ -1327,20 +1346,7 @@ __global__ void __launch_bounds__(256) k_shade_finish(const RenderParams p, int 
       }
       const f3 rL = mk(R.lx, R.ly, R.lz);
       const float nl = (float)p.n_lights;
-      const float d = dot(N, rL); // :775
-      if (!(d <= 0.f)) {          // :777
-        const DevMat M = p.mat[mi];                   // :768
-        f3 c = ld3(M.ka) * 0.5f + ld3(M.ke);          // :769-770
-        if (nl != 1.f) c = c / nl;                    // x / 1.0f == x bit for bit
-        const f3 Hh = normalize((N + rL) * 2.f);      // :780
-        const float sp = powf(dot(N, Hh), M.Ns);
-        f3 ds = ld3(M.kd) * d + ld3(M.ks) * sp;       // :782-783
-        if (nl != 1.f) ds = ds / nl;
-        c = c + ds;
-        r += c.x;                                      // :786-788
-        g += c.y;
-        b += c.z;
-      }
+      phong_add(p.mat[mi], N, rL, nl, r, g, b); // :768-788
     }
     if (MULTI && !last) {
       p.sq.state[npx + px] = r;

@@ -498,7 +498,7 @@ def test_triangle_group_record_bounds():
 
 
 def test_committed_profile_was_measured_on_these_sources():
-    """profiles/current.json feeds bench.py's roofline.traffic and `kernels` view; bench.py drops
+    """profiles/current.json feeds bench.py's roofline.traffic and `valu` view; bench.py drops
     it (traffic: null) when its stamp -- sha256 over csrc/* and the Makefile -- is not the tree's.
     The committed state must not be in that condition."""
     import json
@@ -509,4 +509,11 @@ def test_committed_profile_was_measured_on_these_sources():
     cur = json.load(open(os.path.join(root, "profiles", "current.json")))
     assert cur["source_stamp"] == ns["source_stamp"](), \
         "csrc/ or the Makefile changed after the last tools/profile.sh + summarize_prof.py --current run"
-    assert cur["hbm_bytes_per_frame"] > 0 and set(cur["valu_insts_per_frame"]) == {"k_primary", "k_shade"}
+    # both sweeps are profiled: the default (grouped) path and the linear brute-force path
+    assert set(cur["paths"]) == {"grouped", "linear"}
+    for path in cur["paths"].values():
+        assert path["hbm_bytes_per_frame"] > 0
+        for kern in path["kernels"].values():
+            for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU",
+                      "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"):
+                assert kern.get(c, 0) > 0, c
