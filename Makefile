@@ -17,7 +17,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
 LIB_SRC  := $(PKG)/csrc/rt_kernels.hip $(PKG)/csrc/rt_capi.cpp $(PKG)/csrc/rt_multi.cpp \
             $(PKG)/host/host_core.cpp $(PKG)/host/obj_loader.cpp $(PKG)/host/synth.cpp \
             $(PKG)/host/accel_build.cpp
-LIB_HDR  := include/esctp1_rt.h $(PKG)/csrc/rt_device.h $(PKG)/csrc/rt_math.h $(PKG)/csrc/rt_brute.h $(PKG)/csrc/rt_accel.h $(PKG)/host/scene.h $(PKG)/host/accel_build.h
+LIB_HDR  := include/esctp1_rt.h $(PKG)/csrc/rt_device.h $(PKG)/csrc/rt_math.h $(PKG)/csrc/rt_brute.h $(PKG)/csrc/rt_accel.h $(PKG)/csrc/rt_lists.h $(PKG)/csrc/rt_tile_math.h $(PKG)/host/scene.h $(PKG)/host/accel_build.h
 
 all: lib viewer oracle
 

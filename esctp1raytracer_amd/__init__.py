@@ -14,14 +14,14 @@ import numpy as np
 from . import _capi
 from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_BVH, ESC_STAGE_LDS,
                     ESC_RENDER_EXACT_ONLY, ESC_RENDER_INDEX_ORDER, ESC_RENDER_SHADE_FUSED,
-                    ESC_RENDER_SHADE_QUEUE, ESC_RENDER_TIME_KERNELS,
+                    ESC_RENDER_SHADE_QUEUE, ESC_RENDER_TIME_KERNELS, ESC_RENDER_NO_TILE_LISTS,
                     ESC_STAGE_SMEM, EscError,
                     check)
 
 __all__ = ["Scene", "Camera", "Renderer", "FlatScene", "MultiRenderer", "render_multi", "render_multi_rccl", "rccl_available", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
            "EscError", "ESC_FACE_FIXED", "ESC_FACE_HASH", "ESC_STAGE_AUTO", "ESC_STAGE_SMEM",
            "ESC_STAGE_LDS", "ESC_STAGE_BVH", "ESC_RENDER_EXACT_ONLY", "ESC_RENDER_TIME_KERNELS", "ESC_RENDER_INDEX_ORDER", "ESC_RENDER_SHADE_QUEUE",
-           "ESC_RENDER_SHADE_FUSED", "version"]
+           "ESC_RENDER_SHADE_FUSED", "ESC_RENDER_NO_TILE_LISTS", "version"]
 
 
 def _f32(a, shape=None):
@@ -361,6 +361,19 @@ class Renderer:
         return {"primary_rays": c.primary_rays, "hit_pixels": c.hit_pixels,
                 "shadow_rays": c.shadow_rays, "anyhit_tests": c.anyhit_tests,
                 "anyhit_lane_tests": c.anyhit_lane_tests}
+
+
+    def tile_lists(self, which):
+        """the tile lists of the last frame (0: sphere groups, 1: triangle groups) -> dict with the
+        header numbers and the per-tile counts, or None when the frame used none"""
+        hdr = (C.c_int32 * 8)()
+        n = check(self._lib.esc_tile_list_counts(self._h, which, hdr, None, 0))
+        if n == 0:
+            return None
+        cnt = np.zeros(n, np.int32)
+        check(self._lib.esc_tile_list_counts(self._h, which, hdr, cnt.ctypes.data_as(C.POINTER(C.c_int32)), n))
+        return {"global": hdr[0], "cones": hdr[1], "off": hdr[2], "tiles_x": hdr[3], "tile_rows": hdr[4],
+                "cap": hdr[5], "global_cap": hdr[6], "counts": cnt.reshape(hdr[4], hdr[3])}
 
 
 def strip_local_rows(H, strip_rows, first_strip, strip_stride):

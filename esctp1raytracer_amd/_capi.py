@@ -32,6 +32,7 @@ ESC_RENDER_TIME_KERNELS = 2
 ESC_RENDER_INDEX_ORDER = 4
 ESC_RENDER_SHADE_QUEUE = 8
 ESC_RENDER_SHADE_FUSED = 16
+ESC_RENDER_NO_TILE_LISTS = 32
 
 
 class EscError(RuntimeError):
@@ -149,6 +150,10 @@ SIGNATURES = {
     "esc_queue_schedule": (C.c_int, [C.c_int32, C.c_int32, _I32, C.c_int32]),
     "esc_tri_group_record": (C.c_int, [_F, C.c_int32, _F]),
     "esc_sphere_group_record": (C.c_int, [_F, C.c_int32, _F]),
+    "esc_tile_list_counts": (C.c_int, [C.c_void_p, C.c_int32, _I32, _I32, C.c_size_t]),
+    "esc_tile_rect": (C.c_int, [C.POINTER(esc_camera), C.c_int32, C.c_int32, _F, C.c_double, _I32]),
+    "esc_tile_cone": (C.c_int, [C.POINTER(esc_camera), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.POINTER(C.c_double)]),
     "esc_group_order": (C.c_int, [_F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _I32]),
     "esc_last_kernel_ms": (C.c_int, [_P, _F]),
     "esc_reset_counters": (C.c_int, [_P]),

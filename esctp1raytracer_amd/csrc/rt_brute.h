@@ -516,26 +516,32 @@ DEVINL uint32_t sph8_primary_mask(const SphF2 (&S)[8], const V3<v2f> &d) {
 // reference arithmetic.  Hyper-group y holds super-groups [8 y, 8 y + 8), super-group s groups
 // [8 s, 8 s + 8), group g the sorted slots [8 g, 8 g + 8); n_hyp is a multiple of 8 (pad records
 // never pass).
+// the 8 member spheres of leaf group g (sorted slots [8 g, 8 g + 8)): filter, then the reference
+// arithmetic on the flagged halves
+template <typename FetchF, typename FetchE, typename FetchI>
+DEVINL void sph_group_members_primary(FetchF recf, FetchE rece, FetchI reci, int g, int base,
+                                      const V3<v2f> &d, Hit (&h)[2]) {
+  SphF2 S[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) S[i] = recf(8 * g + i);
+  const uint32_t mask = sph8_primary_mask(S, d);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (mask & (0xFu << (4 * j))) {
+      DevSphP E[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) E[i] = rece(8 * g + 4 * j + i);
+      test_sph_primary_sorted(E, reci(2 * g + j), base, d, h);
+    }
+}
+
 template <typename FetchF, typename FetchE, typename FetchI>
 DEVINL void closest_sph_primary_groups(FetchF recy, FetchF recu, FetchF recg, FetchF recf, FetchE rece,
                                        FetchI reci, int n_hyp, int base, const V3<v2f> &d,
                                        Hit (&h)[2]) {
   static_assert(kSphGroup == 8 && kSphSuper == 8 && kSphHyper == 8 && kSphGroupStep == 8,
                 "8-wide bodies below");
-  auto members = [&](int g) {
-    SphF2 S[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) S[i] = recf(8 * g + i);
-    const uint32_t mask = sph8_primary_mask(S, d);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (mask & (0xFu << (4 * j))) {
-        DevSphP E[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) E[i] = rece(8 * g + 4 * j + i);
-        test_sph_primary_sorted(E, reci(2 * g + j), base, d, h);
-      }
-  };
+  auto members = [&](int g) { sph_group_members_primary(recf, rece, reci, g, base, d, h); };
   auto groups = [&](int s) {
     SphF2 G[8];
 #pragma unroll
@@ -847,44 +853,54 @@ DEVINL void test_tri2_primary_sorted(const DevTriP (&T)[2], int id0, int id1, co
 // n_hyp is a multiple of kTriGroupStep (= 4; pad records never open).  Hyper-group y holds
 // super-groups [kTriHyper y, kTriHyper (y + 1)), super-group s groups [kTriSuper s, kTriSuper (s + 1)),
 // group g the sorted slots [8 g, 8 g + 8).
+// pre-filter body on 4 records x 2 pixels: per-lane flags of the two record pairs
+DEVINL void tri4_primary_flags(const TriPF (&T)[4], const V3<v2f> &d, v2f (&b)[4], v2f (&g)[4], bool &f0,
+                               bool &f1) {
+  tri4_primary_prefilter_pk(T, d.x, d.y, d.z, b, g);
+  float mx0 = 0.f, mn0 = 2.f, mx1 = 0.f, mn1 = 2.f;
+  maxmin_abs4(b[0], b[1], g[0], g[1], mx0, mn0);
+  maxmin_abs4(b[2], b[3], g[2], g[3], mx1, mn1);
+  f0 = (mx0 >= 1.f) | (mn0 <= 1.f);
+  f1 = (mx1 >= 1.f) | (mn1 <= 1.f);
+}
+// sorted triangles k .. k+3 (k a multiple of 4): pre-filter; flagged pairs: filter; flagged again:
+// the reference arithmetic, an equal closest t going to the lower ORIGINAL index
+template <typename FetchP, typename FetchF, typename FetchE, typename FetchI>
+DEVINL void tri_members4_primary(FetchP recp, FetchF recf, FetchE rece, FetchI reci, int k,
+                                 const V3<v2f> &d, Hit (&h)[2]) {
+  auto level2 = [&](int k2) { // sorted triangles k2, k2+1 (k2 even)
+    const TriF T[2] = {recf(k2), recf(k2 + 1)};
+    v2f A[2], B[2], C[2];
+    tri2_primary_filter_pk(T, d.x, d.y, d.z, A, B, C);
+    const int m = tri_flags(A[1], B[1], C[1], tri_flags(A[0], B[0], C[0], -1));
+    if (ANY_LANE_RARE(m >= 0)) {
+      const DevTriP E[2] = {rece(k2), rece(k2 + 1)};
+      const DevIdx4 I = reci(k2 >> 2);
+      test_tri2_primary_sorted(E, (k2 & 2) ? I.v[2] : I.v[0], (k2 & 2) ? I.v[3] : I.v[1], d, h);
+    }
+  };
+  TriPF T[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) T[i] = recp(k + i);
+  v2f b[4], g[4];
+  bool f0, f1;
+  tri4_primary_flags(T, d, b, g, f0, f1);
+  if (ANY_LANE_RARE(f0 | f1)) {
+    if (__builtin_amdgcn_ballot_w64(f0)) level2(k);
+    if (__builtin_amdgcn_ballot_w64(f1)) level2(k + 2);
+  }
+}
+
 template <typename FetchP, typename FetchF, typename FetchE, typename FetchI>
 DEVINL void closest_tri_primary_groups(FetchP recy, FetchP recu, FetchP recg, FetchP recp, FetchF recf,
                                        FetchE rece, FetchI reci, int n_hyp, const V3<v2f> &d,
                                        Hit (&h)[2]) {
   static_assert(kTriGroup == 8 && kTriSuper % 4 == 0 && kTriHyper % 4 == 0 && kTriGroupStep == 4,
                 "4-wide bodies below");
-  auto level2 = [&](int k) { // sorted triangles k, k+1 (k even)
-    const TriF T[2] = {recf(k), recf(k + 1)};
-    v2f A[2], B[2], C[2];
-    tri2_primary_filter_pk(T, d.x, d.y, d.z, A, B, C);
-    const int m = tri_flags(A[1], B[1], C[1], tri_flags(A[0], B[0], C[0], -1));
-    if (ANY_LANE_RARE(m >= 0)) {
-      const DevTriP E[2] = {rece(k), rece(k + 1)};
-      const DevIdx4 I = reci(k >> 2);
-      test_tri2_primary_sorted(E, (k & 2) ? I.v[2] : I.v[0], (k & 2) ? I.v[3] : I.v[1], d, h);
-    }
-  };
-  // pre-filter body on 4 records x 2 pixels: per-lane flags of the two record pairs
   auto flags4 = [&](const TriPF(&T)[4], v2f (&b)[4], v2f (&g)[4], bool &f0, bool &f1) {
-    tri4_primary_prefilter_pk(T, d.x, d.y, d.z, b, g);
-    float mx0 = 0.f, mn0 = 2.f, mx1 = 0.f, mn1 = 2.f;
-    maxmin_abs4(b[0], b[1], g[0], g[1], mx0, mn0);
-    maxmin_abs4(b[2], b[3], g[2], g[3], mx1, mn1);
-    f0 = (mx0 >= 1.f) | (mn0 <= 1.f);
-    f1 = (mx1 >= 1.f) | (mn1 <= 1.f);
+    tri4_primary_flags(T, d, b, g, f0, f1);
   };
-  auto members4 = [&](int k) { // sorted triangles k .. k+3: pre-filter, filter, reference arithmetic
-    TriPF T[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) T[i] = recp(k + i);
-    v2f b[4], g[4];
-    bool f0, f1;
-    flags4(T, b, g, f0, f1);
-    if (ANY_LANE_RARE(f0 | f1)) {
-      if (__builtin_amdgcn_ballot_w64(f0)) level2(k);
-      if (__builtin_amdgcn_ballot_w64(f1)) level2(k + 2);
-    }
-  };
+  auto members4 = [&](int k) { tri_members4_primary(recp, recf, rece, reci, k, d, h); };
   // wave-uniform mask of the records (groups / super-groups) some lane must open
   auto open4 = [&](const TriPF(&T)[4]) -> uint32_t {
     v2f b[4], g[4];

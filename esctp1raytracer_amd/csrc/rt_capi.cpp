@@ -16,6 +16,7 @@
 #include "../host/accel_build.h"
 #include "../host/scene.h"
 #include "rt_device.h"
+#include "rt_tile_math.h"
 
 static_assert(sizeof(esc_bvh_node) == sizeof(esc::BvhNode) && sizeof(esc::BvhNode) == 64,
               "esc_bvh_node is the public face of esc::BvhNode");
@@ -27,6 +28,7 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
+extern "C" int esc_launch_tile_lists(const esc::RenderParams *p, hipStream_t stream);
 extern "C" int esc_launch_bin_primary(const esc::RenderParams *p, const esc::PrimBoxDev *tri_boxes,
                                       const esc::PrimBoxDev *sph_boxes, hipStream_t stream);
 extern "C" int esc_launch_bin_light(const esc::LightBins *g, const float *light_points,
@@ -88,6 +90,15 @@ struct esc_context {
   float prepared_origin[3] = {0, 0, 0};
   int32_t *d_hits = nullptr; // k_primary -> k_shade hand-over: 3 planes (idx, t, v) of hits_cap dwords
   size_t hits_cap = 0;
+  // tile lists of the primary pass (rt_device.h TileLists), valid for list_key
+  esc::TileLists sl{}, tl{};
+  size_t list_tiles_cap = 0;
+  struct ListKey {
+    float cam[12];
+    int32_t W, H, h0, n_local_rows, strip_rows, strip_step, n_sg, n_tg;
+  } list_key{};
+  bool lists_valid = false;
+  bool list_ids_stale = false; // a new scene: ids of the old one may be out of range
   // ESC_STAGE_BVH: host copy of the tables the builder reads, the tree in HBM
   std::vector<esc::DevTri> h_tri;
   std::vector<esc::DevSph> h_sph;
@@ -813,6 +824,8 @@ int commit(esc_context *ctx, const Staged &s) {
                                     : std::min(ctx->min_light_faces, (int)s.lights[i].n_faces);
   ctx->have_scene = true;
   ctx->prepared = false;
+  ctx->lists_valid = false;
+  ctx->list_ids_stale = true;
   ctx->h_tri = s.tri;
   ctx->h_sph = s.sph;
   ctx->h_light_points = s.light_points;
@@ -1389,6 +1402,72 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     std::memcpy(ctx->prepared_origin, cam->origin, 12);
     ctx->prepared = true;
   }
+  // ---- tile lists of the primary pass (rt_lists.h): per camera and band, cached while both stand
+  {
+    static const bool env_nolists = [] {
+      const char *e = std::getenv("ESC_LISTS");
+      return e && std::strcmp(e, "0") == 0;
+    }();
+    const bool want = !env_nolists && !(opts->flags & ESC_RENDER_NO_TILE_LISTS) && p.use_filter &&
+                      (p.sg.n_grp > 0 || p.tg.n_grp > 0) && opts->stage != ESC_STAGE_LDS &&
+                      opts->stage != ESC_STAGE_BVH && (h0 % 4) == 0;
+    if (want) {
+      const int tiles_x = (W + 31) / 32, tile_rows = (n_local_rows + 3) / 4;
+      const size_t n_tiles = (size_t)tiles_x * tile_rows;
+      if (n_tiles > ctx->list_tiles_cap || !ctx->sl.hdr) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); // an earlier frame may still read the old lists
+        void *old[] = {ctx->sl.hdr, ctx->sl.cnt, ctx->sl.ids, ctx->tl.hdr, ctx->tl.cnt, ctx->tl.ids,
+                       ctx->tl.esc};
+        for (void *q : old)
+          if (q) HIP_TRY(hipFree(q));
+        ctx->sl = esc::TileLists{};
+        ctx->tl = esc::TileLists{};
+        ctx->list_tiles_cap = 0;
+        ctx->lists_valid = false;
+        int rc;
+        for (esc::TileLists *L : {&ctx->sl, &ctx->tl}) {
+          if ((rc = alloc_dev(L->hdr, (size_t)esc::kTileHdrInts))) return rc;
+          if ((rc = alloc_dev(L->cnt, n_tiles))) return rc;
+          if ((rc = alloc_dev(L->ids, n_tiles * esc::kTileListCap))) return rc;
+          // slots past a count are read in whole batches of 4: zeros are valid slots
+          HIP_TRY(hipMemsetAsync(L->ids, 0, n_tiles * esc::kTileListCap * 4, ctx->stream));
+        }
+        if ((rc = alloc_dev(ctx->tl.esc, (size_t)esc::kTileEscCap))) return rc;
+        ctx->list_tiles_cap = n_tiles;
+      }
+      esc_context::ListKey key;
+      std::memset(&key, 0, sizeof(key));
+      std::memcpy(key.cam, cam->origin, 12);
+      std::memcpy(key.cam + 3, cam->lower_left_corner, 12);
+      std::memcpy(key.cam + 6, cam->horizontal, 12);
+      std::memcpy(key.cam + 9, cam->vertical, 12);
+      key.W = W; key.H = H; key.h0 = h0; key.n_local_rows = n_local_rows;
+      key.strip_rows = strip_rows; key.strip_step = strip_step;
+      key.n_sg = p.sg.n_grp; key.n_tg = p.tg.n_grp;
+      p.sl = ctx->sl;
+      p.tl = ctx->tl;
+      p.sl.tiles_x = p.tl.tiles_x = tiles_x;
+      p.sl.tile_rows = p.tl.tile_rows = tile_rows;
+      p.sl.enabled = p.sg.n_grp > 0;
+      p.tl.enabled = p.tg.n_grp > 0;
+      if (!ctx->lists_valid || std::memcmp(&key, &ctx->list_key, sizeof(key)) != 0) {
+        for (const esc::TileLists *L : {&p.sl, &p.tl}) {
+          HIP_TRY(hipMemsetAsync(L->hdr, 0, (size_t)esc::kTileHdrInts * 4, ctx->stream));
+          HIP_TRY(hipMemsetAsync(L->cnt, 0, n_tiles * 4, ctx->stream));
+          if (ctx->list_ids_stale) // slots past a count are read in whole batches: keep them valid
+            HIP_TRY(hipMemsetAsync(L->ids, 0, ctx->list_tiles_cap * esc::kTileListCap * 4, ctx->stream));
+        }
+        ctx->list_ids_stale = false;
+        int e = esc_launch_tile_lists(&p, ctx->stream);
+        if (e) {
+          set_error(std::string("k_bin_*_groups launch: ") + hipGetErrorString((hipError_t)e));
+          return ESC_ERR_HIP;
+        }
+        ctx->list_key = key;
+        ctx->lists_valid = true;
+      }
+    }
+  }
   int stage = (opts->stage == ESC_STAGE_LDS) ? 2 : 1; // AUTO -> SMEM (measured)
   // pixels per work-item of the PRIMARY pass; AUTO = 2 (measured)
   int px = opts->pixels_per_lane ? opts->pixels_per_lane : 2;
@@ -1601,6 +1680,73 @@ int esc_sphere_group_record(const float *cxyzr2, int32_t count, float record[4])
   const esc::DevSphGroup g = esc::group_bounds(sph, order.data(), count);
   std::memcpy(record, &g, 16);
   return ESC_OK;
+}
+
+namespace {
+void camera_params(const esc_camera *cam, int32_t W, int32_t H, esc::RenderParams &p) {
+  std::memset(&p, 0, sizeof(p));
+  std::memcpy(p.origin, cam->origin, 12);
+  std::memcpy(p.llc, cam->lower_left_corner, 12);
+  std::memcpy(p.horizontal, cam->horizontal, 12);
+  std::memcpy(p.vertical, cam->vertical, 12);
+  p.W = W;
+  p.H = H;
+}
+} // namespace
+
+int esc_tile_list_counts(esc_context *ctx, int32_t which, int32_t hdr[8], int32_t *counts,
+                         size_t capacity) {
+  if (!ctx || !hdr || (which != 0 && which != 1)) {
+    set_error("esc_tile_list_counts: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  const esc::TileLists &L = which ? ctx->tl : ctx->sl;
+  const int n_groups = which ? ctx->list_key.n_tg : ctx->list_key.n_sg;
+  if (!ctx->lists_valid || !L.hdr || n_groups == 0) return 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int32_t h[3];
+  HIP_TRY(hipMemcpy(h, L.hdr, sizeof(h), hipMemcpyDeviceToHost));
+  const int tiles_x = (ctx->list_key.W + 31) / 32, tile_rows = (ctx->list_key.n_local_rows + 3) / 4;
+  const int32_t out[8] = {h[0], h[1], h[2], tiles_x, tile_rows, esc::kTileListCap, esc::kTileGlobalCap, 0};
+  std::memcpy(hdr, out, sizeof(out));
+  const size_t n_tiles = (size_t)tiles_x * tile_rows;
+  if (counts)
+    HIP_TRY(hipMemcpy(counts, L.cnt, std::min(capacity, n_tiles) * 4, hipMemcpyDeviceToHost));
+  return (int)n_tiles;
+}
+
+int esc_tile_rect(const esc_camera *cam, int32_t W, int32_t H, const float centre[3], double radius,
+                  int32_t rect[4]) {
+  if (!cam || !centre || !rect || W < 2 || H < 2 || !(radius > 0.0)) {
+    set_error("esc_tile_rect: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  esc::RenderParams p;
+  camera_params(cam, W, H, p);
+  const esc::CamD c = esc::cam_frame(p);
+  if (!c.ok) return 0;
+  const double rel[3] = {(double)centre[0] - c.o[0], (double)centre[1] - c.o[1], (double)centre[2] - c.o[2]};
+  int w0 = 0, w1 = -1, h0 = 0, h1 = -1;
+  const int st = esc::sphere_pixel_rect(c, W, H, rel, radius, w0, w1, h0, h1);
+  rect[0] = w0; rect[1] = w1; rect[2] = h0; rect[3] = h1;
+  return st;
+}
+
+int esc_tile_cone(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, int32_t row,
+                  double out[4]) {
+  if (!cam || !out || W < 2 || H < 2) {
+    set_error("esc_tile_cone: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  esc::RenderParams p;
+  camera_params(cam, W, H, p);
+  const esc::CamD c = esc::cam_frame(p);
+  if (!c.ok) return 0;
+  double a[3], delta = 0.0;
+  if (!esc::tile_cone(p, c, tile_x, row, a, delta)) return 0;
+  out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = delta;
+  return 1;
 }
 
 int esc_group_order(const float *xyz, int32_t count, int32_t run, int32_t big, int32_t huge,

@@ -253,6 +253,39 @@ struct TriGroups {
   const DevTriPairPF *grp2_pf;   // n_grp / 2 records, then n_sup / 2, then n_hyp / 2
 };
 
+// ---------------------------------------------------------------------------------------
+// Tile lists for PRIMARY rays (rt_lists.h): which primitives can the rays of one wave's pixel tile
+// (32 columns x 4 rows of the band) touch at all?  All primary rays leave one point, so the
+// statements the filters rest on -- "the ray's line passes within D_i of the sphere's centre", "the
+// line meets the triangle's plane within rho_t of the triangle, or the ray is nearly parallel to
+// that plane" -- are regions of the image: k_bin_spheres / k_bin_triangles project every primitive
+// once per camera and band (in double) and append its slot in the group-sorted table to the tiles
+// of that rectangle; k_bin_tri_escape adds the triangles whose "nearly parallel" band a tile's rays
+// can fall into.  The primary pass then tests its tile's primitives directly -- no sweep over the
+// group levels.  A list that overflows, a frame with too many "always test" primitives, a band
+// that does not start on a multiple of 4 rows: the tile falls back to the three-level sweep.
+// Nothing computed from a list reaches the image.
+// ---------------------------------------------------------------------------------------
+constexpr int kTileListCap = 96;    // primitives per tile (a multiple of 4)
+constexpr int kTileGlobalCap = 64;  // primitives every tile tests (the camera beside them, slivers)
+constexpr int kTileMaxSpan = 8192;  // tiles one primitive may be appended to before it goes global
+constexpr int kTileEscCap = 4096;   // triangles the camera is nearly in the plane of (more: lists off this frame)
+constexpr int kTileHdrInts = 8 + kTileGlobalCap; // [0] n global, [1] n cone entries, [2] lists off, [8..) global ids
+struct alignas(16) TileEsc { // one triangle whose "nearly parallel" escape rays of this frame can take
+  float ax, ay, az, kp;      // |d . n| <= kp
+  int32_t id, pad[3];        // slot in the sorted table
+};
+struct TileLists {
+  int32_t *hdr;      // kTileHdrInts
+  int32_t *cnt;      // [tiles_x * tile_rows] appended ids (may exceed the cap: that tile falls back)
+  int32_t *ids;      // [tiles][kTileListCap]
+  TileEsc *esc;      // [kTileEscCap] (triangle groups only)
+  int32_t tiles_x;   // ceil(W / 32)
+  int32_t tile_rows; // ceil(n_local_rows / 4)
+  int32_t enabled;   // 0: no lists (the sweep over the levels)
+  int32_t pad;
+};
+
 // hand-over between k_primary and k_shade: the closest hit of every pixel of the band
 // (main.cpp:715-722 state) as three planes of n_pixels dwords each, so every store / load is a
 // run of consecutive dwords:
@@ -430,6 +463,7 @@ struct RenderParams {
   unsigned long long *counters;
   SphGroups sg;                 // sphere groups (both passes)
   TriGroups tg;                 // triangle groups (both passes)
+  TileLists sl, tl;             // primary rays: tile lists of sphere / triangle leaf groups
   ShadeQueue sq;                // queue form of the shadow pass (brute force, large scenes)
   HitPlanes hits;               // band-local, n_local_rows * W pixels (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only

@@ -40,6 +40,7 @@
 #include "rt_device.h"
 #include "rt_math.h"
 #include "rt_brute.h"
+#include "rt_lists.h"
 #include "rt_accel.h"
 
 namespace esc {
@@ -198,54 +199,6 @@ __global__ void __launch_bounds__(256) k_prepare_groups(const SphGroups g, float
     }
     g.grp_f[i] = F;
   }
-}
-
-// (P) of rt_brute.h "Triangle GROUPS": may a ray from the camera o be accepted by triangle T through
-// the pre-filter's "nearly parallel" escape at all?  Only if the camera lies within H of T's plane.
-// Everything in fp32 from T's own record; 1 % + 16u |tvec| on top of H cover the roundings, and
-// every doubtful case (a sliver, a non-finite value) answers yes with no usable normal.
-struct TriEscape {
-  bool possible; // the camera is within H of the plane (or nothing can be said)
-  bool bounded;  // nh / beta below are valid: the escape needs |d . nh| < beta
-  f3 nh;         // unit normal
-  float beta;    // tau / |n1| for this camera
-};
-DEVINL TriEscape tri_escape(const DevTri &T, f3 o, float slack_k) {
-  TriEscape E;
-  E.possible = true;
-  E.bounded = false;
-  E.nh = mk(0.f, 0.f, 0.f);
-  E.beta = 0.f;
-  const float u = 0x1p-24f;
-  const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
-  if (e1.x == 0.f && e1.y == 0.f && e1.z == 0.f && e2.x == 0.f && e2.y == 0.f && e2.z == 0.f) {
-    E.possible = false; // pad slot (or a point): det == 0 exactly, rejected
-    return E;
-  }
-  const f3 tv = o - ld3(T.v0);
-  const f3 n1 = cross(e2, e1);
-  const float nn = sqrtf(dot(n1, n1));
-  const float a1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z);
-  const float a2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
-  const float at = (fabsf(tv.x) + fabsf(tv.y)) + fabsf(tv.z);
-  const float l1 = sqrtf(dot(e1, e1)), l2 = sqrtf(dot(e2, e2));
-  const f3 s3 = (e1 + e2) * (1.f / 3.f);
-  const float rho = sqrtf(fmaxf(fmaxf(dot(s3, s3), dot(e1 - s3, e1 - s3)), dot(e2 - s3, e2 - s3)));
-  const float emax = fmaxf(l1, l2);
-  if (!(rho > 0x1.2p-10f * emax) || !(nn > 0.f)) return E; // sliver / no normal
-  const float p12 = a1 * a2;
-  const float k = 3.2f * u * emax / rho * 1.0001f / slack_k; // this level's threshold tau / k
-  const float tau = k * ((10.04f * a2 + 5.04f * a1) * at + 20.1f * p12);
-  if (!(tau < 0.1f * nn)) return E; // |d . n| < 0.1 is part of the argument
-  const float ted = (tau + 10.05f * u * p12) * (1.f + 4.f * u);
-  const float U = ted + 10.04f * u * at * a2, V = ted + 5.04f * u * at * a1;
-  const float H = (fmaxf(V / l1, U / l2) + at * tau / nn) * (2.f * l1 * l2 / nn) * (1.f / 0.99f);
-  const float h = fabsf(dot(tv, n1)) / nn;
-  E.possible = !(h > H * 1.01f + 0x1p-20f * at); // NaN: yes
-  E.nh = n1 * (1.f / nn);
-  E.beta = tau / nn;
-  E.bounded = (E.nh.x == E.nh.x) && (E.nh.y == E.nh.y) && (E.nh.z == E.nh.z) && (E.beta == E.beta);
-  return E;
 }
 
 // per-frame records of the triangle groups (rt_device.h TriGroups): the sorted triangles' forms,
@@ -672,16 +625,32 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
   // ---- main.cpp:722 closest hit over every primitive
   V3<V> dv[NV];
   pack3<V, NV>(dir, dv);
+  // this wave's 32 x 4 pixel tile in the band (rt_device.h TileLists); a wave wholly outside the
+  // band has nothing to test
+  const int tile_x = (T.w0 >> 5) + (T.wave & 1), tile_y = (T.lr0 >> 2) + (T.wave >> 1);
+  const int tiles_x = (p.W + 31) >> 5;
+  const bool tile_ok = tile_x < tiles_x && tile_y * 4 < p.n_local_rows;
+  const int tile = tile_y * tiles_x + tile_x;
   if (STAGE == STAGE_SMEM) {
     if constexpr (PX == 2) {
       if (GRP && p.use_filter && p.tg.n_grp > 0) {
-        closest_tri_primary_groups(
-            SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp + p.tg.n_sup},
-            SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp},
-            SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf)},
-            SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.sorted_pf)},
-            SmemFetch<TriF>{reinterpret_cast<const TriF *>(p.tg.sorted_f)},
-            SmemFetch<DevTriP>{p.tg.sorted_p}, SmemFetch<DevIdx4>{p.tg.orig}, p.tg.n_hyp, dv[0], hit);
+        const SmemFetch<TriPF> recp{reinterpret_cast<const TriPF *>(p.tg.sorted_pf)};
+        const SmemFetch<TriF> recf{reinterpret_cast<const TriF *>(p.tg.sorted_f)};
+        const SmemFetch<DevTriP> rece{p.tg.sorted_p};
+        const SmemFetch<DevIdx4> reci{p.tg.orig};
+        bool listed = false;
+        if (p.tl.enabled) // this tile's triangles straight away (rt_lists.h)
+          listed = !tile_ok ||
+                   sweep_tile_list(p.tl, tile, [&](int i0, int i1, int i2, int i3) {
+                     tri2_listed_primary(recf, rece, reinterpret_cast<const int32_t *>(p.tg.orig), i0, i1, dv[0], hit);
+                     tri2_listed_primary(recf, rece, reinterpret_cast<const int32_t *>(p.tg.orig), i2, i3, dv[0], hit);
+                   });
+        if (!listed)
+          closest_tri_primary_groups(
+              SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp + p.tg.n_sup},
+              SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf) + p.tg.n_grp},
+              SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tg.grp_pf)}, recp, recf, rece, reci,
+              p.tg.n_hyp, dv[0], hit);
       } else {
       const int n2 = (p.use_filter && p.n_tri >= 8) ? (p.n_tri & ~3) : 0;
       closest_tri_primary_filter(SmemFetch<TriPF>{reinterpret_cast<const TriPF *>(p.tri_pf)},
@@ -695,13 +664,22 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     if constexpr (PX == 2) {
       // multiples of 8 through the hand-scheduled packed bodies, the tail through the generic one
       if (GRP && p.use_filter && p.sg.n_grp > 0) {
-        closest_sph_primary_groups(
-            SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp + p.sg.n_sup},
-            SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp},
-            SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f)},
-            SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.sorted_f)},
-            SmemFetch<DevSphP>{p.sg.sorted_p}, SmemFetch<DevIdx4>{p.sg.orig}, p.sg.n_hyp, p.n_tri,
-            dv[0], hit);
+        const SmemFetch<SphF2> recf{reinterpret_cast<const SphF2 *>(p.sg.sorted_f)};
+        const SmemFetch<DevSphP> rece{p.sg.sorted_p};
+        const SmemFetch<DevIdx4> reci{p.sg.orig};
+        bool listed = false;
+        if (p.sl.enabled)
+          listed = !tile_ok ||
+                   sweep_tile_list(p.sl, tile, [&](int i0, int i1, int i2, int i3) {
+                     sph4_listed_primary(rece, reinterpret_cast<const int32_t *>(p.sg.orig), i0, i1, i2, i3,
+                                         p.n_tri, dv[0], hit);
+                   });
+        if (!listed)
+          closest_sph_primary_groups(
+              SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp + p.sg.n_sup},
+              SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f) + p.sg.n_grp},
+              SmemFetch<SphF2>{reinterpret_cast<const SphF2 *>(p.sg.grp_f)}, recf, rece, reci, p.sg.n_hyp,
+              p.n_tri, dv[0], hit);
       } else {
       const int n8 = p.n_sph & ~7;
       if (p.use_filter)
@@ -1424,6 +1402,19 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
   if (sg->n_grp > 0)
     hipLaunchKernelGGL(esc::k_prepare_groups, dim3((sg->n_grp * esc::kSphGroup + 255) / 256),
                        dim3(256), 0, stream, *sg, p->origin[0], p->origin[1], p->origin[2]);
+  return (int)hipGetLastError();
+}
+
+// tile lists of the primary pass (rt_lists.h): hdr / cnt zeroed by the caller on this stream; after
+// esc_launch_prepare (the triangle groups' frame cones)
+extern "C" int esc_launch_tile_lists(const esc::RenderParams *p, hipStream_t stream) {
+  if (p->sl.enabled && p->sg.n_grp > 0)
+    hipLaunchKernelGGL(esc::k_bin_spheres, dim3(p->sg.n_grp * esc::kSphGroup / 4), dim3(256), 0, stream, *p);
+  if (p->tl.enabled && p->tg.n_grp > 0) {
+    hipLaunchKernelGGL(esc::k_bin_triangles, dim3(p->tg.n_grp * esc::kTriGroup / 4), dim3(256), 0, stream, *p);
+    const int n_tiles = p->tl.tiles_x * p->tl.tile_rows;
+    hipLaunchKernelGGL(esc::k_bin_tri_escape, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, *p);
+  }
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,327 @@
+// rt_lists.h -- tile lists for primary rays (rt_device.h TileLists): the kernels that build them
+// and the list-driven form of the primary sweep.  Included by rt_kernels.hip only.
+//
+// Tile lists.  A wave of the primary pass owns a tile of 32 x 4 pixels.  Instead of sweeping the
+// hyper-groups and opening super-groups, groups and members on the way down, it reads the list of
+// the PRIMITIVES (slots of the group-sorted tables) some ray of its tile may have to test and runs
+// the member code of the sweep on them: spheres straight through the reference arithmetic
+// (test_sph_primary_sorted), triangles through the triangle filter and, behind it, the reference
+// arithmetic (tri2_primary_filter_pk, test_tri2_primary_sorted).  What makes a list complete is the
+// statement the filters already rest on (rt_brute.h "Sphere GROUPS", "Triangle pre-filter",
+// "Triangle GROUPS" (P)), for a ray from the camera o with the reference's fp32 direction d:
+//   sphere i not rejected at `disc < 0`  ==>  the LINE o + l d passes within
+//        D_i = r_i (1+u) + 4.41 sqrt(u) |oc_i|_1 + 2^-74   of c~_i = o - fl(o - c_i);
+//   triangle t accepted  ==>  (S_t) the line through o'_t meets t's plane at a point X* within rho_t
+//        of t IN THAT PLANE (X* = v0 + u* e1 + v* e2), o'_t within 1.01u |tvec|_1 of o,
+//        or (E_t) |d . n_t| < tau_t / |n1_t| -- and (P) that only with the camera within H_t of the plane.
+// All three are regions of the image plane:
+//  * "The line along p passes within R of c = C - o" for p(s, t) = A + s H + t V (A = llc - o, s =
+//    w / (W-1), t = h / (H-1): camera.h:31-34) is p^T M p <= 0 with M = (|c|^2 - R^2) I - c c^T, a
+//    conic in (s, t).  With x = (s, t, 1), p = B x, B = [H V A], the lines s = const tangent to it
+//    solve Qi_33 s^2 - 2 Qi_13 s + Qi_11 = 0 with Qi = (B^T M B)^-1 ~ B^-1 (I - c c^T / R^2) B^-T, i.e.
+//    Qi_jk = b_j . b_k - (b_j . c)(b_k . c) / R^2 over the rows b_1, b_2, b_3 of B^-1 (t: b_2).  Qi_33 < 0
+//    <=> the sphere lies wholly on one side of the camera plane parallel to the image; otherwise the
+//    region is unbounded and the primitive goes to the short list every tile tests.  The double
+//    cone has both nappes, so a sphere BEHIND the camera is binned where its lines cross the image
+//    -- more than needed (an accept needs t2 > 0), never less.  Evaluated in double from the fp32
+//    inputs; what fp32 rounding does to the rays grows the rectangle: the reference evaluates
+//    ((llc + H s) + V t) - o in fp32 and normalises, which moves p by at most eps_p = 2^-19 (|llc|_1 +
+//    |H|_1 + |V|_1 + |o|_1) (16u would do), i.e. the ray's (s, t) by at most (|b_1| + |b_3|) eps_p 1.01
+//    resp. (|b_2| + |b_3|) eps_p 1.01; one more pixel covers fl(w / (W-1)) and the floor / ceil
+//    (rt_tile_math.h; tests/test_tile_lists.py checks it per pixel by brute force).
+//  * (S_t): the in-plane disc of radius rho' around a point lies in the in-plane square of half-side
+//    rho', so t dilated by rho' in its plane lies in the convex hull of the 12 corners v_i +- rho' e_a
+//    +- rho' e_b (e_a, e_b orthonormal in the plane), and the rays that meet a convex hull are those
+//    through the hull of its projection (all 12 on one side of the camera plane; else the triangle
+//    is global): the rectangle is the union of the 12 points' rectangles,
+//    each taken as a ball of radius 2^-20 (|tvec|_1 + |e1|_1 + |e2|_1) for o'_t vs o and the evaluation
+//    of the points.  rho' = rho_t (1 + 1e-5) + that same slack.  Slivers (the pre-filter passes them
+//    on for every ray) are global.
+//  * (E_t): k_bin_triangles evaluates (P) per triangle (tri_escape, the function the group cones are
+//    built from); a triangle the camera is nearly in the plane of leaves a cone entry (n_t, beta_t),
+//    and k_bin_tri_escape appends it to every tile whose centre direction a has |a . n_t| <= beta_t
+//    + delta, delta the chord within which all directions of the tile lie (the largest deviation
+//    over a planar convex patch is at a corner: {p : angle(p, a) <= theta} is convex).
+// Whatever cannot be listed -- a tile with more than kTileListCap primitives, more than
+// kTileGlobalCap global ones, more than kTileEscCap cone entries, a singular camera frame, a band
+// that does not start on a multiple of 4 rows -- takes the three-level sweep instead (the consumer
+// returns false): lists only ever REPLACE the question "what may this tile's rays touch" and never
+// a test.  The order of the tests is free: an equal closest t goes to the lower original index.
+// Slots of a list past its count hold ids of earlier frames of the same scene or zeros -- valid
+// slots either way, and testing a primitive twice or needlessly cannot change a closest hit -- so
+// lists are read in whole batches of 4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_brute.h"
+#include "rt_device.h"
+#include "rt_math.h"
+#include "rt_tile_math.h"
+
+namespace esc {
+
+DEVINL void list_global(const TileLists &L, int id) {
+  const int slot = atomicAdd(&L.hdr[0], 1);
+  if (slot < kTileGlobalCap) L.hdr[8 + slot] = id;
+}
+
+// append `id` to every tile of the band that the pixel rectangle overlaps, the wave side by side;
+// global when the rectangle spans very many tiles
+DEVINL void list_rect(const RenderParams &p, const TileLists &L, int w0, int w1, int h0, int h1, int id,
+                      int lane) {
+  const int tx0 = w0 >> 5, tx1 = w1 >> 5, j0 = h0 >> 2, j1 = h1 >> 2;
+  if ((long long)(tx1 - tx0 + 1) * (j1 - j0 + 1) > kTileMaxSpan) {
+    if (lane == 0) list_global(L, id);
+    return;
+  }
+  const int nx = tx1 - tx0 + 1, n = nx * (j1 - j0 + 1);
+  for (int k = lane; k < n; k += 64) {
+    const int r4 = band_tile_row(p, j0 + k / nx);
+    if (r4 < 0) continue;
+    const int tile = r4 * L.tiles_x + tx0 + k % nx;
+    const int slot = atomicAdd(&L.cnt[tile], 1);
+    if (slot < kTileListCap) L.ids[(size_t)tile * kTileListCap + slot] = id;
+  }
+}
+
+// one wave per slot of the group-sorted sphere table
+__global__ void __launch_bounds__(256) k_bin_spheres(const RenderParams p) {
+  const int s = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63u);
+  if (s >= p.sg.n_grp * kSphGroup) return;
+  const DevSph S = p.sg.sorted[s];
+  if (!(S.r2 >= 0.f)) return; // pad slot (r2 = -inf): never hit
+  const TileLists L = p.sl;
+  const CamD cam = cam_frame(p);
+  if (!cam.ok) {
+    if (lane == 0) L.hdr[2] = 1;
+    return;
+  }
+  const double c[3] = {(double)S.cx - cam.o[0], (double)S.cy - cam.o[1], (double)S.cz - cam.o[2]};
+  const double A1 = fabs(c[0]) + fabs(c[1]) + fabs(c[2]);
+  // D_i of rt_brute.h "Sphere GROUPS" (4.41 * 2^-12 < 0x1.2p-10), a little larger, + c~_i vs c_i
+  const double R = (sqrt((double)S.r2) + 0x1.2p-10 * A1) * (1.0 + 0x1p-20) + 0x1p-22 * A1 + 0x1p-60;
+  int w0, w1, h0, h1;
+  const int st = sphere_pixel_rect(cam, p.W, p.H, c, R, w0, w1, h0, h1);
+  if (st == 2) return; // off screen
+  if (st == 0) {
+    if (lane == 0) list_global(L, s);
+    return;
+  }
+  list_rect(p, L, w0, w1, h0, h1, s, lane);
+}
+
+// (P) of rt_brute.h "Triangle GROUPS": may a ray from the camera o be accepted by triangle T through
+// the pre-filter's "nearly parallel" escape at all?  Only if the camera lies within H of T's plane.
+// Everything in fp32 from T's own record; 1 % + 16u |tvec| on top of H cover the roundings, and
+// every doubtful case (a sliver, a non-finite value) answers yes with no usable normal.
+struct TriEscape {
+  bool possible; // the camera is within H of the plane (or nothing can be said)
+  bool bounded;  // nh / beta below are valid: the escape needs |d . nh| < beta
+  f3 nh;         // unit normal
+  float beta;    // tau / |n1| for this camera
+};
+DEVINL TriEscape tri_escape(const DevTri &T, f3 o, float slack_k) {
+  TriEscape E;
+  E.possible = true;
+  E.bounded = false;
+  E.nh = mk(0.f, 0.f, 0.f);
+  E.beta = 0.f;
+  const float u = 0x1p-24f;
+  const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
+  if (e1.x == 0.f && e1.y == 0.f && e1.z == 0.f && e2.x == 0.f && e2.y == 0.f && e2.z == 0.f) {
+    E.possible = false; // pad slot (or a point): det == 0 exactly, rejected
+    return E;
+  }
+  const f3 tv = o - ld3(T.v0);
+  const f3 n1 = cross(e2, e1);
+  const float nn = sqrtf(dot(n1, n1));
+  const float a1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z);
+  const float a2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
+  const float at = (fabsf(tv.x) + fabsf(tv.y)) + fabsf(tv.z);
+  const float l1 = sqrtf(dot(e1, e1)), l2 = sqrtf(dot(e2, e2));
+  const f3 s3 = (e1 + e2) * (1.f / 3.f);
+  const float rho = sqrtf(fmaxf(fmaxf(dot(s3, s3), dot(e1 - s3, e1 - s3)), dot(e2 - s3, e2 - s3)));
+  const float emax = fmaxf(l1, l2);
+  if (!(rho > 0x1.2p-10f * emax) || !(nn > 0.f)) return E; // sliver / no normal
+  const float p12 = a1 * a2;
+  const float k = 3.2f * u * emax / rho * 1.0001f / slack_k; // this level's threshold tau / k
+  const float tau = k * ((10.04f * a2 + 5.04f * a1) * at + 20.1f * p12);
+  if (!(tau < 0.1f * nn)) return E; // |d . n| < 0.1 is part of the argument
+  const float ted = (tau + 10.05f * u * p12) * (1.f + 4.f * u);
+  const float U = ted + 10.04f * u * at * a2, V = ted + 5.04f * u * at * a1;
+  const float H = (fmaxf(V / l1, U / l2) + at * tau / nn) * (2.f * l1 * l2 / nn) * (1.f / 0.99f);
+  const float h = fabsf(dot(tv, n1)) / nn;
+  E.possible = !(h > H * 1.01f + 0x1p-20f * at); // NaN: yes
+  E.nh = n1 * (1.f / nn);
+  E.beta = tau / nn;
+  E.bounded = (E.nh.x == E.nh.x) && (E.nh.y == E.nh.y) && (E.nh.z == E.nh.z) && (E.beta == E.beta);
+  return E;
+}
+
+
+// one wave per slot of the group-sorted triangle table: global / (S_t) rectangle / (E_t) cone entry
+__global__ void __launch_bounds__(256) k_bin_triangles(const RenderParams p) {
+  const int k = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63u);
+  if (k >= p.tg.n_grp * kTriGroup) return;
+  const DevTri T = p.tg.sorted[k];
+  const f3 e1f = ld3(T.e1), e2f = ld3(T.e2);
+  if (e1f.x == 0.f && e1f.y == 0.f && e1f.z == 0.f && e2f.x == 0.f && e2f.y == 0.f && e2f.z == 0.f)
+    return; // pad slot (or a point): det == 0 exactly, never accepted
+  const TileLists L = p.tl;
+  const CamD cam = cam_frame(p);
+  if (!cam.ok) {
+    if (lane == 0) L.hdr[2] = 1;
+    return;
+  }
+  const double e1[3] = {e1f.x, e1f.y, e1f.z}, e2[3] = {e2f.x, e2f.y, e2f.z};
+  const double v0[3] = {(double)T.v0[0] - cam.o[0], (double)T.v0[1] - cam.o[1], (double)T.v0[2] - cam.o[2]};
+  double n1[3];
+  cross3(e2, e1, n1);
+  const double nn = sqrt(dot3(n1, n1)), l1 = sqrt(dot3(e1, e1)), l2 = sqrt(dot3(e2, e2));
+  const double s3[3] = {(e1[0] + e2[0]) / 3.0, (e1[1] + e2[1]) / 3.0, (e1[2] + e2[2]) / 3.0};
+  const double q1[3] = {e1[0] - s3[0], e1[1] - s3[1], e1[2] - s3[2]}, q2[3] = {e2[0] - s3[0], e2[1] - s3[1], e2[2] - s3[2]};
+  const double rho = sqrt(fmax(fmax(dot3(s3, s3), dot3(q1, q1)), dot3(q2, q2)));
+  const double emax = fmax(l1, l2);
+  // (P) / (E_t) per triangle, with the function the group cones are built from
+  const TriEscape E = tri_escape(T, mk(p.origin[0], p.origin[1], p.origin[2]), 1.f);
+  const bool sliver = !(rho > 0x1.4p-10 * emax) || !(nn > 0.0) || !(l1 > 0.0); // (the pre-filter's own
+                                                                                // threshold is 2^-10)
+  if (sliver || (E.possible && !E.bounded)) { // passed on for every ray
+    if (lane == 0) list_global(L, k);
+    return;
+  }
+  if (E.possible && lane == 0) { // the camera is nearly in this plane: k_bin_tri_escape bins the band
+    const int slot = atomicAdd(&L.hdr[1], 1);
+    if (slot < kTileEscCap) {
+      TileEsc X;
+      X.ax = E.nh.x;
+      X.ay = E.nh.y;
+      X.az = E.nh.z;
+      X.kp = E.beta * 1.0001f + 0x1p-20f; // fp32 beta and normal, |d| - 1
+      X.id = k;
+      X.pad[0] = X.pad[1] = X.pad[2] = 0;
+      L.esc[slot] = X;
+    }
+  }
+  // (S_t): lanes 0..11 take the corners v_i +- rho' e_a +- rho' e_b
+  const double at = (fabs(v0[0]) + fabs(v0[1]) + fabs(v0[2])) + (fabs(e1[0]) + fabs(e1[1]) + fabs(e1[2])) +
+                    (fabs(e2[0]) + fabs(e2[1]) + fabs(e2[2]));
+  const double slack = 0x1p-20 * at + 0x1p-60;
+  const double rp = rho * (1.0 + 1e-5) + slack;
+  const double ea[3] = {e1[0] / l1, e1[1] / l1, e1[2] / l1};
+  double eb[3];
+  cross3(n1, ea, eb);
+  for (int j = 0; j < 3; ++j) eb[j] /= nn;
+  const int cn = lane % 12, vi = cn >> 2;
+  const double sa = (cn & 1) ? rp : -rp, sb = (cn & 2) ? rp : -rp;
+  double pt[3];
+  for (int j = 0; j < 3; ++j)
+    pt[j] = v0[j] + (vi == 1 ? e1[j] : 0.0) + (vi == 2 ? e2[j] : 0.0) + sa * ea[j] + sb * eb[j];
+  double ext[4], depth = 0.0;
+  const bool bounded = sphere_pixel_extent(cam, p.W, p.H, pt, slack, ext, &depth);
+  // a corner in the camera plane, or corners on both sides of it: the hull of the projections
+  // says nothing (the triangle's image runs through infinity)
+  const unsigned long long front = __builtin_amdgcn_ballot_w64(depth > 0.0);
+  if (__builtin_amdgcn_ballot_w64(!bounded) != 0 || (front != 0 && front != ~0ull)) {
+    if (lane == 0) list_global(L, k);
+    return;
+  }
+  for (int off = 32; off > 0; off >>= 1) { // union over the lanes (12 distinct corners, repeated)
+    ext[0] = fmin(ext[0], __shfl_xor(ext[0], off));
+    ext[1] = fmax(ext[1], __shfl_xor(ext[1], off));
+    ext[2] = fmin(ext[2], __shfl_xor(ext[2], off));
+    ext[3] = fmax(ext[3], __shfl_xor(ext[3], off));
+  }
+  int w0, w1, h0, h1;
+  if (extent_rect(ext, p.W, p.H, w0, w1, h0, h1) == 2) return; // off screen
+  list_rect(p, L, w0, w1, h0, h1, k, lane);
+}
+
+// (E_t): one thread per tile against every cone entry of the frame
+__global__ void __launch_bounds__(256) k_bin_tri_escape(const RenderParams p) {
+  const TileLists L = p.tl;
+  const int tile = blockIdx.x * 256 + (int)threadIdx.x;
+  if (tile >= L.tiles_x * L.tile_rows) return;
+  const int n_esc = L.hdr[1];
+  if (n_esc == 0) return;
+  if (n_esc > kTileEscCap) {
+    L.hdr[2] = 1; // too many cones: the sweep handles this frame
+    return;
+  }
+  const CamD cam = cam_frame(p);
+  if (!cam.ok) return; // (hdr[2] already set by k_bin_triangles)
+  const int tx = tile % L.tiles_x, r4 = tile / L.tiles_x;
+  double a[3], delta;
+  if (!tile_cone(p, cam, tx, band_image_row(p, 4 * r4), a, delta)) {
+    L.hdr[2] = 1; // a degenerate direction: nothing can be said
+    return;
+  }
+  const float ax = (float)a[0], ay = (float)a[1], az = (float)a[2];
+  const float df = (float)delta * 1.0001f + 0x1p-20f; // a in fp32, the fp32 dot product below
+  for (int k = 0; k < n_esc; ++k) {
+    const TileEsc X = L.esc[k];
+    const float da = ax * X.ax + ay * X.ay + az * X.az;
+    if (fabsf(da) <= X.kp + df) {
+      const int slot = atomicAdd(&L.cnt[tile], 1);
+      if (slot < kTileListCap) L.ids[(size_t)tile * kTileListCap + slot] = X.id;
+    }
+  }
+}
+
+// ---- the list-driven primary sweep.  `tile` is wave-uniform.  false: this tile has no usable list.
+typedef const int32_t __attribute__((address_space(4))) *ListPtr;
+
+// body4(i0, i1, i2, i3): test four listed slots
+template <typename Body4> DEVINL bool sweep_tile_list(const TileLists &L, int tile, Body4 body4) {
+  const ListPtr hdr = (ListPtr)(uintptr_t)L.hdr;
+  const int n_glob = hdr[0];
+  if (hdr[2] != 0 || n_glob > kTileGlobalCap) return false;
+  const int n = ((ListPtr)(uintptr_t)L.cnt)[tile];
+  if (n > kTileListCap) return false;
+  const SmemFetch<DevIdx4> glob{reinterpret_cast<const DevIdx4 *>(L.hdr + 8)};
+  for (int k = 0; k < n_glob; k += 4) {
+    const DevIdx4 I = glob(k >> 2);
+    body4(I.v[0], I.v[1], I.v[2], I.v[3]);
+  }
+  const SmemFetch<DevIdx4> ids{reinterpret_cast<const DevIdx4 *>(L.ids + (size_t)tile * kTileListCap)};
+  for (int k = 0; k < n; k += 4) {
+    const DevIdx4 I = ids(k >> 2);
+    body4(I.v[0], I.v[1], I.v[2], I.v[3]);
+  }
+  return true;
+}
+
+// four listed spheres (slots of the sorted table): the reference arithmetic, ties to the lower
+// original index
+template <typename FetchE>
+DEVINL void sph4_listed_primary(FetchE rece, const int32_t *orig, int i0, int i1, int i2, int i3, int base,
+                                const V3<v2f> &d, Hit (&h)[2]) {
+  const ListPtr og = (ListPtr)(uintptr_t)orig;
+  const DevSphP E[4] = {rece(i0), rece(i1), rece(i2), rece(i3)};
+  DevIdx4 O;
+  O.v[0] = og[i0];
+  O.v[1] = og[i1];
+  O.v[2] = og[i2];
+  O.v[3] = og[i3];
+  test_sph_primary_sorted(E, O, base, d, h);
+}
+
+// two listed triangles: the triangle filter, then the reference arithmetic
+template <typename FetchF, typename FetchE>
+DEVINL void tri2_listed_primary(FetchF recf, FetchE rece, const int32_t *orig, int k0, int k1,
+                                const V3<v2f> &d, Hit (&h)[2]) {
+  const TriF T[2] = {recf(k0), recf(k1)};
+  v2f A[2], B[2], C[2];
+  tri2_primary_filter_pk(T, d.x, d.y, d.z, A, B, C);
+  const int m = tri_flags(A[1], B[1], C[1], tri_flags(A[0], B[0], C[0], -1));
+  if (ANY_LANE_RARE(m >= 0)) {
+    const ListPtr og = (ListPtr)(uintptr_t)orig;
+    const DevTriP E[2] = {rece(k0), rece(k1)};
+    test_tri2_primary_sorted(E, og[k0], og[k1], d, h);
+  }
+}
+
+} // namespace esc

@@ -1,0 +1,154 @@
+// rt_tile_math.h -- the geometry behind the tile lists (rt_lists.h), host + device: the camera frame
+// in double, the pixel rectangle of a bounding sphere, the direction cone of a tile.  Shared with
+// rt_capi.cpp, which exposes it to the CPU tests (esc_tile_rect / esc_tile_cone): what the tests
+// check against per-pixel brute force is this very code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+
+namespace esc {
+
+#define HDINL __host__ __device__ __forceinline__
+
+struct CamD { // the camera frame in double: rows of [H V A]^-1 and what fp32 rounding can move a ray by
+  double o[3];
+  double b1[3], b2[3], b3[3];
+  double nb1, nb2, nb3; // their lengths
+  double eps_p;
+  bool ok;
+};
+HDINL double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+HDINL void cross3(const double *a, const double *b, double *r) {
+  r[0] = a[1] * b[2] - a[2] * b[1];
+  r[1] = a[2] * b[0] - a[0] * b[2];
+  r[2] = a[0] * b[1] - a[1] * b[0];
+}
+HDINL CamD cam_frame(const RenderParams &p) {
+  CamD c;
+  double Hh[3], V[3], A[3], m1 = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    c.o[k] = p.origin[k];
+    Hh[k] = p.horizontal[k];
+    V[k] = p.vertical[k];
+    A[k] = (double)p.llc[k] - c.o[k];
+    m1 += fabs((double)p.llc[k]) + fabs(Hh[k]) + fabs(V[k]) + fabs(c.o[k]);
+  }
+  double hv[3], va[3], ah[3];
+  cross3(Hh, V, hv);
+  cross3(V, A, va);
+  cross3(A, Hh, ah);
+  const double det = dot3(A, hv);
+  const double scale = sqrt(dot3(A, A) * dot3(Hh, Hh) * dot3(V, V));
+  c.ok = fabs(det) > 1e-9 * scale && scale > 0.0 && scale < 1e150; // also false for NaN
+  const double id = c.ok ? 1.0 / det : 0.0;
+  for (int k = 0; k < 3; ++k) {
+    c.b1[k] = va[k] * id;
+    c.b2[k] = ah[k] * id;
+    c.b3[k] = hv[k] * id;
+  }
+  c.nb1 = sqrt(dot3(c.b1, c.b1));
+  c.nb2 = sqrt(dot3(c.b2, c.b2));
+  c.nb3 = sqrt(dot3(c.b3, c.b3));
+  c.eps_p = 0x1p-19 * m1;
+  return c;
+}
+
+// image row of local row lr of the band (the Tile<> mapping of rt_kernels.hip)
+HDINL int band_image_row(const RenderParams &p, int lr) {
+  return p.h0 + (lr / p.strip_rows) * p.strip_step + (lr % p.strip_rows);
+}
+// local tile row (4 rows) that holds image rows [4 j, 4 j + 4), or -1; p.h0 is a multiple of 4
+HDINL int band_tile_row(const RenderParams &p, int j) {
+  const int rel = 4 * j - p.h0;
+  if (rel < 0) return -1;
+  int lr = rel;
+  if (p.strip_step > 0) {
+    const int k = rel / p.strip_step, off = rel % p.strip_step;
+    if (off >= p.strip_rows) return -1;
+    lr = k * p.strip_rows + off;
+  }
+  if (lr >= p.n_local_rows) return -1;
+  return lr >> 2;
+}
+
+// Pixel extents ext = {wlo, whi, hlo, hhi} (double, NOT clipped to the image, grown by what fp32
+// rounding can move a ray) outside which no primary ray's line passes within R of c (= C - o).
+// false: unbounded (the camera plane cuts the sphere) or nothing can be said.  depth (optional)
+// receives b_3 . c: its sign tells on which side of the camera plane the sphere lies (the lines of
+// a sphere behind the camera cross the image point-mirrored -- a CONVEX HULL of several spheres'
+// extents is only meaningful when all of them lie on one side).
+HDINL bool sphere_pixel_extent(const CamD &cam, int W, int H, const double c[3], double R, double ext[4],
+                               double *depth = nullptr) {
+  const double iR2 = 1.0 / (R * R);
+  const double c1 = dot3(cam.b1, c), c2 = dot3(cam.b2, c), c3 = dot3(cam.b3, c);
+  if (depth) *depth = c3;
+  const double q33 = cam.nb3 * cam.nb3 - c3 * c3 * iR2;
+  if (!(q33 < -1e-9 * cam.nb3 * cam.nb3)) return false; // the camera plane cuts the sphere (or NaN)
+  const double q11 = cam.nb1 * cam.nb1 - c1 * c1 * iR2, q13 = dot3(cam.b1, cam.b3) - c1 * c3 * iR2;
+  const double q22 = cam.nb2 * cam.nb2 - c2 * c2 * iR2, q23 = dot3(cam.b2, cam.b3) - c2 * c3 * iR2;
+  const double ds = sqrt(fmax(0.0, q13 * q13 - q11 * q33)), dt = sqrt(fmax(0.0, q23 * q23 - q22 * q33));
+  const double sa = (q13 - ds) / q33, sb = (q13 + ds) / q33;
+  const double ta = (q23 - dt) / q33, tb = (q23 + dt) / q33;
+  const double W1 = (double)(W - 1), H1 = (double)(H - 1);
+  const double pw = 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1;
+  const double ph = 1.0 + (cam.nb2 + cam.nb3) * cam.eps_p * 1.01 * H1;
+  const double big = 1e9;
+  ext[0] = fmax(-big, fmin(big, fmin(sa, sb) * W1 - pw));
+  ext[1] = fmax(-big, fmin(big, fmax(sa, sb) * W1 + pw));
+  ext[2] = fmax(-big, fmin(big, fmin(ta, tb) * H1 - ph));
+  ext[3] = fmax(-big, fmin(big, fmax(ta, tb) * H1 + ph));
+  return ext[0] == ext[0] && ext[1] == ext[1] && ext[2] == ext[2] && ext[3] == ext[3]; // NaN: no
+}
+// extents -> the pixel rectangle clipped to the image; 1: rectangle, 2: wholly off screen
+HDINL int extent_rect(const double ext[4], int W, int H, int &w0, int &w1, int &h0, int &h1) {
+  w0 = (int)floor(ext[0]) < 0 ? 0 : (int)floor(ext[0]);
+  w1 = (int)ceil(ext[1]) > W - 1 ? W - 1 : (int)ceil(ext[1]);
+  h0 = (int)floor(ext[2]) < 0 ? 0 : (int)floor(ext[2]);
+  h1 = (int)ceil(ext[3]) > H - 1 ? H - 1 : (int)ceil(ext[3]);
+  return (w0 > w1 || h0 > h1) ? 2 : 1;
+}
+// both: 0 unbounded / unusable, 1 rectangle, 2 wholly off screen
+HDINL int sphere_pixel_rect(const CamD &cam, int W, int H, const double c[3], double R, int &w0, int &w1,
+                            int &h0, int &h1) {
+  double ext[4];
+  if (!sphere_pixel_extent(cam, W, H, c, R, ext)) return 0;
+  return extent_rect(ext, W, H, w0, w1, h0, h1);
+}
+
+// Centre direction a (unit) of the pixels [32 tx, 32 tx + 32) x [h, h + 4) and a chord delta such
+// that every ray direction the reference computes for them lies within delta of a.  false: a
+// degenerate direction, nothing can be said.
+HDINL bool tile_cone(const RenderParams &p, const CamD &cam, int tx, int h, double a[3], double &delta) {
+  const double W1 = (double)(p.W - 1), H1 = (double)(p.H - 1);
+  const double pw = 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1;
+  const double ph = 1.0 + (cam.nb2 + cam.nb3) * cam.eps_p * 1.01 * H1;
+  const double s0 = (32.0 * tx - pw) / W1, s1 = (32.0 * tx + 31.0 + pw) / W1;
+  const double t0 = ((double)h - ph) / H1, t1 = ((double)h + 3.0 + ph) / H1;
+  double Hh[3], V[3], A[3];
+  for (int k = 0; k < 3; ++k) {
+    Hh[k] = p.horizontal[k];
+    V[k] = p.vertical[k];
+    A[k] = (double)p.llc[k] - cam.o[k];
+  }
+  auto dir = [&](double s, double t, double *d) {
+    for (int k = 0; k < 3; ++k) d[k] = A[k] + s * Hh[k] + t * V[k];
+    const double n = sqrt(dot3(d, d));
+    for (int k = 0; k < 3; ++k) d[k] /= n;
+  };
+  double q[3];
+  dir(0.5 * (s0 + s1), 0.5 * (t0 + t1), a);
+  delta = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    dir((k & 1) ? s1 : s0, (k & 2) ? t1 : t0, q);
+    const double e[3] = {q[0] - a[0], q[1] - a[1], q[2] - a[2]};
+    delta = fmax(delta, sqrt(dot3(e, e)));
+  }
+  if (!(delta == delta)) return false;
+  delta = delta * 1.0001 + 1e-6;
+  return true;
+}
+
+} // namespace esc

@@ -245,7 +245,16 @@ enum {
    * lights, or ESC_RENDER_INDEX_ORDER; a single light's grouped lists always take the fused form,
    * the only one that sweeps groups.  These force one. */
   ESC_RENDER_SHADE_QUEUE = 8,
-  ESC_RENDER_SHADE_FUSED = 16
+  ESC_RENDER_SHADE_FUSED = 16,
+  /* Primary rays of grouped tables do not sweep the group levels: per camera and band the library
+   * lists, for every 32 x 4 pixel tile, the primitives its rays can touch (the projection of each
+   * sphere grown by what the reference's rounding can reach, of each triangle dilated in its plane
+   * by its bounding radius, plus the tiles a triangle's "nearly parallel" band crosses:
+   * csrc/rt_lists.h), and a wavefront tests its tile's primitives directly.  Same filters and
+   * reference arithmetic behind the lists, same image.  This flag (or $ESC_LISTS=0) keeps the
+   * three-level sweep of round 2 for every tile -- the A/B switch and a cross-check in tests; tiles
+   * whose lists overflow take that sweep anyway. */
+  ESC_RENDER_NO_TILE_LISTS = 32
 };
 
 typedef struct {
@@ -362,6 +371,28 @@ int esc_tri_group_record(const float *v0e1e2, int32_t count, float record[12]);
 /* The same for spheres (csrc/rt_device.h DevSphGroup): cxyzr2 holds 4 floats per sphere (centre,
  * r^2); record receives centre xyz and rgeo >= r_i + |c_i - centre| for every sphere. */
 int esc_sphere_group_record(const float *cxyzr2, int32_t count, float record[4]);
+
+/* Host only, for inspection and tests: the geometry behind the tile lists of the primary pass
+ * (csrc/rt_tile_math.h, the code the binning kernels run).  esc_tile_rect: the pixel rectangle
+ * rect = {w0, w1, h0, h1} (inclusive, clipped to the image) outside which no primary ray's line
+ * passes within `radius` of `centre`; returns 1 (rectangle), 2 (wholly off screen), 0 (unbounded:
+ * the camera plane cuts the sphere -- such a group is tested by every tile) or a negative error.
+ * esc_tile_cone: out = {ax, ay, az, delta}: every direction the reference computes for the pixels
+ * [32 tile_x, 32 tile_x + 32) x [row, row + 4) lies within the chord delta of the unit vector a;
+ * returns 1, or 0 when nothing can be said. */
+int esc_tile_rect(const esc_camera *cam, int32_t W, int32_t H, const float centre[3], double radius,
+                  int32_t rect[4]);
+int esc_tile_cone(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, int32_t row,
+                  double out[4]);
+
+/* For inspection and tests: the tile lists the last frame of this context was rendered with
+ * (which = 0 spheres, 1 triangles).  hdr receives {global primitives, cone entries, lists-off
+ * flag, tiles_x, tile_rows, list capacity, global capacity, 0}; counts (may be NULL) the appended
+ * primitive count of up to `capacity` tiles -- a count above the list capacity means that tile took
+ * the three-level sweep.  Returns the number of tiles, 0 when the context holds no lists, or a
+ * negative error.  Synchronises the context's stream. */
+int esc_tile_list_counts(esc_context *ctx, int32_t which, int32_t hdr[8], int32_t *counts,
+                         size_t capacity);
 
 /* Host only, for inspection and tests: the spatial order the groups are cut from (k-d median
  * splits over the points; csrc/rt_device.h SphGroups / TriGroups).  xyz holds 3 floats per point;
