@@ -1733,20 +1733,26 @@ int esc_tile_rect(const esc_camera *cam, int32_t W, int32_t H, const float centr
   return st;
 }
 
-int esc_tile_cone(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, int32_t row,
-                  double out[4]) {
-  if (!cam || !out || W < 2 || H < 2) {
-    set_error("esc_tile_cone: bad argument");
+int esc_tile_band(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, int32_t row,
+                  const float normal[3], double kp) {
+  if (!cam || !normal || W < 2 || H < 2) {
+    set_error("esc_tile_band: bad argument");
     return ESC_ERR_INVALID;
   }
   esc::RenderParams p;
   camera_params(cam, W, H, p);
   const esc::CamD c = esc::cam_frame(p);
-  if (!c.ok) return 0;
-  double a[3], delta = 0.0;
-  if (!esc::tile_cone(p, c, tile_x, row, a, delta)) return 0;
-  out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = delta;
-  return 1;
+  if (!c.ok) return 1;
+  double st[4], pmax;
+  esc::tile_st_rect(p, c, tile_x, row, st, pmax);
+  if (!(pmax == pmax)) return 1;
+  double fA = 0, fH = 0, fV = 0;
+  for (int j = 0; j < 3; ++j) {
+    fA += ((double)p.llc[j] - c.o[j]) * (double)normal[j];
+    fH += (double)p.horizontal[j] * (double)normal[j];
+    fV += (double)p.vertical[j] * (double)normal[j];
+  }
+  return esc::tile_band_hit(st, pmax, fA, fH, fV, kp) ? 1 : 0;
 }
 
 int esc_group_order(const float *xyz, int32_t count, int32_t run, int32_t big, int32_t huge,

@@ -266,14 +266,15 @@ struct TriGroups {
 // that does not start on a multiple of 4 rows: the tile falls back to the three-level sweep.
 // Nothing computed from a list reaches the image.
 // ---------------------------------------------------------------------------------------
-constexpr int kTileListCap = 96;    // primitives per tile (a multiple of 4)
+constexpr int kTileListCap = 128;   // primitives per tile (a multiple of 4)
 constexpr int kTileGlobalCap = 64;  // primitives every tile tests (the camera beside them, slivers)
 constexpr int kTileMaxSpan = 8192;  // tiles one primitive may be appended to before it goes global
 constexpr int kTileEscCap = 4096;   // triangles the camera is nearly in the plane of (more: lists off this frame)
 constexpr int kTileHdrInts = 8 + kTileGlobalCap; // [0] n global, [1] n cone entries, [2] lists off, [8..) global ids
-struct alignas(16) TileEsc { // one triangle whose "nearly parallel" escape rays of this frame can take
-  float ax, ay, az, kp;      // |d . n| <= kp
-  int32_t id, pad[3];        // slot in the sorted table
+struct alignas(16) TileEsc { // one triangle whose "nearly parallel" escape rays of this frame can take:
+  double fA, fH, fV;         // rays with |p . n| <= kp |p|; p . n = fA + s fH + t fV is affine in the
+  float kp;                  // image-plane coordinates (s, t) of p = A + s H + t V
+  int32_t id;                // slot in the sorted table
 };
 struct TileLists {
   int32_t *hdr;      // kTileHdrInts

@@ -39,9 +39,9 @@
 //    on for every ray) are global.
 //  * (E_t): k_bin_triangles evaluates (P) per triangle (tri_escape, the function the group cones are
 //    built from); a triangle the camera is nearly in the plane of leaves a cone entry (n_t, beta_t),
-//    and k_bin_tri_escape appends it to every tile whose centre direction a has |a . n_t| <= beta_t
-//    + delta, delta the chord within which all directions of the tile lie (the largest deviation
-//    over a planar convex patch is at a corner: {p : angle(p, a) <= theta} is convex).
+//    and k_bin_tri_escape appends it to every tile that holds a ray with |p . n_t| <= beta_t |p|: p . n_t
+//    is affine in (s, t), so its range over the tile's (grown) rectangle is spanned by the corners,
+//    and |p| is at most its largest corner value.
 // Whatever cannot be listed -- a tile with more than kTileListCap primitives, more than
 // kTileGlobalCap global ones, more than kTileEscCap cone entries, a singular camera frame, a band
 // that does not start on a multiple of 4 rows -- takes the three-level sweep instead (the consumer
@@ -197,12 +197,18 @@ __global__ void __launch_bounds__(256) k_bin_triangles(const RenderParams p) {
     const int slot = atomicAdd(&L.hdr[1], 1);
     if (slot < kTileEscCap) {
       TileEsc X;
-      X.ax = E.nh.x;
-      X.ay = E.nh.y;
-      X.az = E.nh.z;
+      const double nh[3] = {E.nh.x, E.nh.y, E.nh.z};
+      double A[3], Hh[3], V[3];
+      for (int j = 0; j < 3; ++j) {
+        A[j] = (double)p.llc[j] - cam.o[j];
+        Hh[j] = p.horizontal[j];
+        V[j] = p.vertical[j];
+      }
+      X.fA = dot3(A, nh);
+      X.fH = dot3(Hh, nh);
+      X.fV = dot3(V, nh);
       X.kp = E.beta * 1.0001f + 0x1p-20f; // fp32 beta and normal, |d| - 1
       X.id = k;
-      X.pad[0] = X.pad[1] = X.pad[2] = 0;
       L.esc[slot] = X;
     }
   }
@@ -254,17 +260,15 @@ __global__ void __launch_bounds__(256) k_bin_tri_escape(const RenderParams p) {
   const CamD cam = cam_frame(p);
   if (!cam.ok) return; // (hdr[2] already set by k_bin_triangles)
   const int tx = tile % L.tiles_x, r4 = tile / L.tiles_x;
-  double a[3], delta;
-  if (!tile_cone(p, cam, tx, band_image_row(p, 4 * r4), a, delta)) {
-    L.hdr[2] = 1; // a degenerate direction: nothing can be said
+  double st[4], pmax;
+  tile_st_rect(p, cam, tx, band_image_row(p, 4 * r4), st, pmax);
+  if (!(pmax == pmax) || !(pmax < 1e150)) {
+    L.hdr[2] = 1; // nothing can be said
     return;
   }
-  const float ax = (float)a[0], ay = (float)a[1], az = (float)a[2];
-  const float df = (float)delta * 1.0001f + 0x1p-20f; // a in fp32, the fp32 dot product below
   for (int k = 0; k < n_esc; ++k) {
     const TileEsc X = L.esc[k];
-    const float da = ax * X.ax + ay * X.ay + az * X.az;
-    if (fabsf(da) <= X.kp + df) {
+    if (tile_band_hit(st, pmax, X.fA, X.fH, X.fV, (double)X.kp) || !(X.fA == X.fA)) {
       const int slot = atomicAdd(&L.cnt[tile], 1);
       if (slot < kTileListCap) L.ids[(size_t)tile * kTileListCap + slot] = X.id;
     }

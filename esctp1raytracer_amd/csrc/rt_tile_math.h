@@ -118,37 +118,34 @@ HDINL int sphere_pixel_rect(const CamD &cam, int W, int H, const double c[3], do
   return extent_rect(ext, W, H, w0, w1, h0, h1);
 }
 
-// Centre direction a (unit) of the pixels [32 tx, 32 tx + 32) x [h, h + 4) and a chord delta such
-// that every ray direction the reference computes for them lies within delta of a.  false: a
-// degenerate direction, nothing can be said.
-HDINL bool tile_cone(const RenderParams &p, const CamD &cam, int tx, int h, double a[3], double &delta) {
+// The image-plane rectangle [s0, s1] x [t0, t1] that holds the (s, t) of every ray the reference
+// computes for the pixels [32 tx, 32 tx + 32) x [h, h + 4) (grown like the sphere rectangles), and
+// pmax >= |A + s H + t V| over it (|p| is convex: the largest value is at a corner).
+HDINL void tile_st_rect(const RenderParams &p, const CamD &cam, int tx, int h, double st[4], double &pmax) {
   const double W1 = (double)(p.W - 1), H1 = (double)(p.H - 1);
   const double pw = 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1;
   const double ph = 1.0 + (cam.nb2 + cam.nb3) * cam.eps_p * 1.01 * H1;
-  const double s0 = (32.0 * tx - pw) / W1, s1 = (32.0 * tx + 31.0 + pw) / W1;
-  const double t0 = ((double)h - ph) / H1, t1 = ((double)h + 3.0 + ph) / H1;
-  double Hh[3], V[3], A[3];
-  for (int k = 0; k < 3; ++k) {
-    Hh[k] = p.horizontal[k];
-    V[k] = p.vertical[k];
-    A[k] = (double)p.llc[k] - cam.o[k];
-  }
-  auto dir = [&](double s, double t, double *d) {
-    for (int k = 0; k < 3; ++k) d[k] = A[k] + s * Hh[k] + t * V[k];
-    const double n = sqrt(dot3(d, d));
-    for (int k = 0; k < 3; ++k) d[k] /= n;
-  };
-  double q[3];
-  dir(0.5 * (s0 + s1), 0.5 * (t0 + t1), a);
-  delta = 0.0;
+  st[0] = (32.0 * tx - pw) / W1;
+  st[1] = (32.0 * tx + 31.0 + pw) / W1;
+  st[2] = ((double)h - ph) / H1;
+  st[3] = ((double)h + 3.0 + ph) / H1;
+  pmax = 0.0;
   for (int k = 0; k < 4; ++k) {
-    dir((k & 1) ? s1 : s0, (k & 2) ? t1 : t0, q);
-    const double e[3] = {q[0] - a[0], q[1] - a[1], q[2] - a[2]};
-    delta = fmax(delta, sqrt(dot3(e, e)));
+    double q[3];
+    for (int j = 0; j < 3; ++j)
+      q[j] = ((double)p.llc[j] - cam.o[j]) + ((k & 1) ? st[1] : st[0]) * (double)p.horizontal[j] +
+             ((k & 2) ? st[3] : st[2]) * (double)p.vertical[j];
+    pmax = fmax(pmax, sqrt(dot3(q, q)));
   }
-  if (!(delta == delta)) return false;
-  delta = delta * 1.0001 + 1e-6;
-  return true;
+  pmax *= 1.0 + 1e-9;
+}
+// can a ray of that rectangle have |d . n| <= kp, d = p / |p|?  p . n = fA + s fH + t fV is affine in
+// (s, t), so its range over the rectangle is spanned by the corners
+HDINL bool tile_band_hit(const double st[4], double pmax, double fA, double fH, double fV, double kp) {
+  const double lo = fA + fmin(st[0] * fH, st[1] * fH) + fmin(st[2] * fV, st[3] * fV);
+  const double hi = fA + fmax(st[0] * fH, st[1] * fH) + fmax(st[2] * fV, st[3] * fV);
+  const double w = kp * pmax + 1e-12 * (fabs(fA) + fabs(fH) + fabs(fV));
+  return lo <= w && hi >= -w; // false for NaN: the caller must have ruled those out
 }
 
 } // namespace esc

@@ -377,13 +377,12 @@ int esc_sphere_group_record(const float *cxyzr2, int32_t count, float record[4])
  * rect = {w0, w1, h0, h1} (inclusive, clipped to the image) outside which no primary ray's line
  * passes within `radius` of `centre`; returns 1 (rectangle), 2 (wholly off screen), 0 (unbounded:
  * the camera plane cuts the sphere -- such a group is tested by every tile) or a negative error.
- * esc_tile_cone: out = {ax, ay, az, delta}: every direction the reference computes for the pixels
- * [32 tile_x, 32 tile_x + 32) x [row, row + 4) lies within the chord delta of the unit vector a;
- * returns 1, or 0 when nothing can be said. */
+ * esc_tile_band: 1 when some ray of the pixels [32 tile_x, 32 tile_x + 32) x [row, row + 4) may
+ * have |d . normal| <= kp (`normal` a unit vector, d the reference's unit direction), else 0. */
 int esc_tile_rect(const esc_camera *cam, int32_t W, int32_t H, const float centre[3], double radius,
                   int32_t rect[4]);
-int esc_tile_cone(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, int32_t row,
-                  double out[4]);
+int esc_tile_band(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, int32_t row,
+                  const float normal[3], double kp);
 
 /* For inspection and tests: the tile lists the last frame of this context was rendered with
  * (which = 0 spheres, 1 triangles).  hdr receives {global primitives, cone entries, lists-off
