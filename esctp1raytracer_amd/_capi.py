@@ -33,6 +33,7 @@ ESC_RENDER_INDEX_ORDER = 4
 ESC_RENDER_SHADE_QUEUE = 8
 ESC_RENDER_SHADE_FUSED = 16
 ESC_RENDER_NO_TILE_LISTS = 32
+ESC_RENDER_NO_LIGHT_LISTS = 64
 
 
 class EscError(RuntimeError):

@@ -29,6 +29,7 @@ extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
 extern "C" int esc_launch_tile_lists(const esc::RenderParams *p, hipStream_t stream);
+extern "C" int esc_launch_light_lists(const esc::RenderParams *p, hipStream_t stream);
 extern "C" int esc_launch_bin_primary(const esc::RenderParams *p, const esc::PrimBoxDev *tri_boxes,
                                       const esc::PrimBoxDev *sph_boxes, hipStream_t stream);
 extern "C" int esc_launch_bin_light(const esc::LightBins *g, const float *light_points,
@@ -99,6 +100,12 @@ struct esc_context {
   } list_key{};
   bool lists_valid = false;
   bool list_ids_stale = false; // a new scene: ids of the old one may be out of range
+  // light lists of the shadow pass (rt_device.h LightLists), valid for (scene, ll_face_mode, ll_fixed_face)
+  esc::LightLists ll{};
+  int ll_alloc_lights = 0;
+  int ll_face_mode = -1, ll_fixed_face = -1;
+  bool ll_valid = false;
+  std::vector<esc::DevLight> h_lights;
   // ESC_STAGE_BVH: host copy of the tables the builder reads, the tree in HBM
   std::vector<esc::DevTri> h_tri;
   std::vector<esc::DevSph> h_sph;
@@ -826,6 +833,8 @@ int commit(esc_context *ctx, const Staged &s) {
   ctx->prepared = false;
   ctx->lists_valid = false;
   ctx->list_ids_stale = true;
+  ctx->ll_valid = false;
+  ctx->h_lights = s.lights;
   ctx->h_tri = s.tri;
   ctx->h_sph = s.sph;
   ctx->h_light_points = s.light_points;
@@ -1465,6 +1474,59 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
         }
         ctx->list_key = key;
         ctx->lists_valid = true;
+      }
+    }
+  }
+  // ---- light lists of the shadow pass (rt_lists.h): per scene and sample point
+  {
+    static const bool env_nollists = [] {
+      const char *e = std::getenv("ESC_LLISTS");
+      return e && std::strcmp(e, "0") == 0;
+    }();
+    int n_listed = 0; // leading lights that offer ONE sample point this frame
+    while (n_listed < std::min(ctx->n_lights, (int)esc::kLightListMax) &&
+           (opts->face_mode == ESC_FACE_FIXED || ctx->h_lights[(size_t)n_listed].n_faces == 1))
+      n_listed++;
+    const bool want = !env_nollists && !(opts->flags & ESC_RENDER_NO_LIGHT_LISTS) && p.use_filter &&
+                      p.shadows && p.sg.n_grp > 0 && n_listed > 0 && opts->stage != ESC_STAGE_LDS &&
+                      opts->stage != ESC_STAGE_BVH;
+    if (want) {
+      const int Rr = esc::kLightListRes;
+      const size_t cells = (size_t)n_listed * 6 * Rr * Rr;
+      if (n_listed > ctx->ll_alloc_lights) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int rc;
+        if ((rc = alloc_dev(ctx->ll.hdr, (size_t)n_listed * 6 * esc::kTileHdrInts))) return rc;
+        if ((rc = alloc_dev(ctx->ll.cnt, cells))) return rc;
+        if ((rc = alloc_dev(ctx->ll.ids, cells * esc::kLightListCap))) return rc;
+        ctx->ll_alloc_lights = n_listed;
+        ctx->ll_valid = false;
+      }
+      esc::LightLists L = ctx->ll;
+      L.n_listed = n_listed;
+      L.R = Rr;
+      L.enabled = 1;
+      for (int li = 0; li < n_listed; li++)
+        L.point[li] = ctx->h_lights[(size_t)li].first_point +
+                      (opts->face_mode == ESC_FACE_FIXED ? opts->fixed_face : 0);
+      p.ll = L;
+      if (!ctx->ll_valid || ctx->ll_face_mode != opts->face_mode ||
+          (opts->face_mode == ESC_FACE_FIXED && ctx->ll_fixed_face != opts->fixed_face) ||
+          ctx->ll.n_listed != n_listed) {
+        HIP_TRY(hipMemsetAsync(L.hdr, 0, (size_t)n_listed * 6 * esc::kTileHdrInts * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(L.cnt, 0, cells * 4, ctx->stream));
+        // spare slots of a cell are read in whole batches of 4: zeros are valid pair records
+        HIP_TRY(hipMemsetAsync(L.ids, 0, cells * esc::kLightListCap * 4, ctx->stream));
+        int e = esc_launch_light_lists(&p, ctx->stream);
+        if (e) {
+          set_error(std::string("k_bin_light_pairs launch: ") + hipGetErrorString((hipError_t)e));
+          return ESC_ERR_HIP;
+        }
+        ctx->ll.n_listed = n_listed;
+        ctx->ll.R = Rr;
+        ctx->ll_face_mode = opts->face_mode;
+        ctx->ll_fixed_face = opts->fixed_face;
+        ctx->ll_valid = true;
       }
     }
   }

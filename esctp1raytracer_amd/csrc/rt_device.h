@@ -287,6 +287,29 @@ struct TileLists {
   int32_t pad;
 };
 
+// ---------------------------------------------------------------------------------------
+// Light lists for SHADOW rays (rt_lists.h "Light lists"): the same idea from the other end.  A
+// light that offers one sample point P this frame (a one-face light, or ESC_FACE_FIXED) has every
+// shadow ray on a line through P, so "which spheres can this ray's line pass within reach of" is a
+// region of the directions around P: a cube map of R x R cells per face, each cell holding the PAIR
+// records (rt_device.h SphGroups::sorted2) with a sphere whose reach disc the cell's directions
+// touch.  Built once per scene and sample point.  A wave looks its rays' cells up, tests those
+// lists with the reference arithmetic and falls back to the three-level group sweep when a cell
+// overflows or a ray starts outside the region the reach was computed for.
+// ---------------------------------------------------------------------------------------
+constexpr int kLightListMax = 4;    // lights (sample points) that get lists
+constexpr int kLightListRes = 128;  // cells per cube-face side
+constexpr int kLightListCap = 64;   // pair records per cell (a multiple of 4)
+struct LightLists {
+  int32_t *hdr;  // [n_listed * 6][kTileHdrInts]: [0] face-global pair records, [2] off, [8..) their ids
+  int32_t *cnt;  // [n_listed * 6 * R * R]
+  int32_t *ids;  // [cells][kLightListCap]
+  int32_t n_listed; // lights 0 .. n_listed - 1 have lists, built for light_points[point[li]]
+  int32_t R;
+  int32_t point[kLightListMax];
+  int32_t enabled, pad;
+};
+
 // hand-over between k_primary and k_shade: the closest hit of every pixel of the band
 // (main.cpp:715-722 state) as three planes of n_pixels dwords each, so every store / load is a
 // run of consecutive dwords:
@@ -464,7 +487,8 @@ struct RenderParams {
   unsigned long long *counters;
   SphGroups sg;                 // sphere groups (both passes)
   TriGroups tg;                 // triangle groups (both passes)
-  TileLists sl, tl;             // primary rays: tile lists of sphere / triangle leaf groups
+  TileLists sl, tl;             // primary rays: tile lists of spheres / triangles
+  LightLists ll;                // shadow rays: light lists of sphere pair records
   ShadeQueue sq;                // queue form of the shadow pass (brute force, large scenes)
   HitPlanes hits;               // band-local, n_local_rows * W pixels (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only

@@ -734,6 +734,7 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
 // TGRP: the scene has triangle groups (rt_device.h TriGroups).  Their sweep needs more registers
 // than 6 waves per SIMD leave (36 B of scratch per lane otherwise), so that variant is built for 5
 // and scenes without triangle groups keep the leaner kernel.
+constexpr int kListServed = 0x40000000; // RepackLds::n_open: this ray's sphere phase ran on light lists
 template <int STAGE, bool TGRP = false>
 __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) k_shade(const RenderParams p) {
   typedef float V;
@@ -994,6 +995,22 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
                 aa[0].orig = reinterpret_cast<const int32_t *>(p.sg.orig);
                 aa[0].orig_bias = aa[0].orig_add = p.n_tri;
               }
+              // a light with one sample point this frame: the cells of its light lists (rt_lists.h)
+              // hold every sphere a ray's line can reach -- unless a ray starts outside the region
+              // the reach was computed for, or its cell overflowed: then the sweep below runs
+              bool served = false;
+              if (p.ll.enabled && li < p.ll.n_listed && n_rec <= kSegGroupPairs &&
+                  __builtin_amdgcn_ballot_w64(aa[0].tb > 0.f && far) == 0) {
+                const f3 Pl = ld3(p.light_points + 4 * p.ll.point[li]);
+                int n_tests = 0, sw = 0;
+                served = anyhit_sph_light_lists(
+                    p.ll, light_list_cell(p.ll, li, Pl, so),
+                    SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2)}, p.n_tri, so, sL, aa[0],
+                    n_tests, sw);
+                n_swept += sw;
+                if (rr >= 0) R.n_open[rr] = (R.n_open[rr] + (n_tests >> 3)) | (served ? kListServed : 0);
+              }
+              if (!served)
               // k0 pair records in = k0 / 4 groups = k0 / 32 super-groups = k0 / 256 hyper-groups; two per record
               n_swept += anyhit_sph_groups_filter(
                   SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) +
@@ -1071,10 +1088,11 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
           unsigned cnt = tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper * kTriHyper) + 1
                                                         : p.tg.n_hyp)
                                     : (unsigned)(by_tri ? k + 1 : p.n_tri);
-          if (!by_tri)
+          // (a ray its light's lists served: the 8-sphere batches it was live for, nothing else)
+          if (!by_tri && !(grp_open & kListServed))
             cnt += sph_groups ? (unsigned)(k >= 0 ? ((k - p.n_tri) >> 9) + 1 : p.sg.n_hyp)
                               : (unsigned)(k >= 0 ? k - p.n_tri + 1 : p.n_sph);
-          cnt_lane = cnt + 8u * (unsigned)grp_open;
+          cnt_lane = cnt + 8u * (unsigned)(grp_open & ~kListServed);
         }
       }
       if (p.shadows && a[0].kocc >= 0) {
@@ -1415,6 +1433,14 @@ extern "C" int esc_launch_tile_lists(const esc::RenderParams *p, hipStream_t str
     const int n_tiles = p->tl.tiles_x * p->tl.tile_rows;
     hipLaunchKernelGGL(esc::k_bin_tri_escape, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, *p);
   }
+  return (int)hipGetLastError();
+}
+
+// light lists of the shadow pass (rt_lists.h): hdr / cnt zeroed by the caller on this stream
+extern "C" int esc_launch_light_lists(const esc::RenderParams *p, hipStream_t stream) {
+  const int n_rec = p->sg.n_grp * (esc::kSphGroup / 2);
+  if (p->ll.n_listed > 0 && n_rec > 0)
+    hipLaunchKernelGGL(esc::k_bin_light_pairs, dim3((n_rec + 3) / 4), dim3(256), 0, stream, *p);
   return (int)hipGetLastError();
 }
 

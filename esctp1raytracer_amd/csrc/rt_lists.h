@@ -328,4 +328,185 @@ DEVINL void tri2_listed_primary(FetchF recf, FetchE rece, const int32_t *orig, i
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Light lists (rt_device.h LightLists).  For a shadow ray (O, L) towards the sample point P, |O - g|_1
+// <= rho_max (rays from further out take the sweep), rt_brute.h "Sphere GROUPS for shadow rays"
+// gives: sphere i not rejected at `disc < 0`  ==>  the ray's LINE passes within
+//     r_i (1+u) + 5.4 sqrt(u) |O - c_i| + 2^-74  <=  r_i (1+u) + 0x1.6p-10 (rho_max + |c_i - g|_1)
+// of c_i.  L = fl(normalize(fl(P - O))) is within 3u of the true direction, so the line also passes
+// within delta = 2^-20 (rho_max + |P - g|_1) of P; shifted by that much it runs through P itself
+// and within R_i = (the reach above) + delta of c_i: the direction from P to the ray's origin lies in
+// the disc of angular radius asin(R_i / |c_i - P|) around c_i - P.  An accept also needs t2 < |P - O|
+// - eps, i.e. the sphere on the ray's side of P -- unless P is (nearly) inside the reach, and such
+// spheres are listed for every direction.  The disc is binned per cube face with the conic bounds
+// of the tile lists (rt_tile_math.h, the face taken as a camera at P) when the sphere lies wholly
+// in front of the face's plane through P; a sphere that plane cuts can only matter to the face if
+// its disc reaches within 54.74 degrees (the face's corner) of the face's axis, and then goes on the
+// face's own short list.  The look-up (light_cell) uses fl(O - P), which is exactly -fl(P - O): within
+// 3u of the line's direction, 3e-5 cells; rectangles are grown by 1e-3 cells.
+// Lists hold PAIR records (two neighbours of the spatial order): the reference arithmetic on
+// pair-interleaved records is what the sweeps' exact path runs (pair2_any_pk).
+// ---------------------------------------------------------------------------------------
+// one wave per pair record of the group-sorted table; every listed light, every face
+__global__ void __launch_bounds__(256) k_bin_light_pairs(const RenderParams p) {
+  const int j = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63u);
+  const int n_rec = p.sg.n_grp * (kSphGroup / 2);
+  if (j >= n_rec) return;
+  const LightLists LL = p.ll;
+  const DevSphPair S = p.sg.sorted2[j];
+  const double g[3] = {p.shadow_center[0], p.shadow_center[1], p.shadow_center[2]};
+  const double rho = (double)p.shadow_rho_max;
+  const int Rr = LL.R, cells_per_face = Rr * Rr;
+  for (int li = 0; li < LL.n_listed; ++li) {
+    const double P[3] = {p.light_points[4 * LL.point[li]], p.light_points[4 * LL.point[li] + 1],
+                         p.light_points[4 * LL.point[li] + 2]};
+    const double delta = 0x1p-20 * (rho + fabs(P[0] - g[0]) + fabs(P[1] - g[1]) + fabs(P[2] - g[2]));
+    double c[2][3], Rh[2], cn[2];
+    bool real[2], around[2];
+    for (int h = 0; h < 2; ++h) {
+      real[h] = S.r2[h] >= 0.f; // pad half: r2 = -inf
+      const double C[3] = {S.cx[h], S.cy[h], S.cz[h]};
+      for (int k = 0; k < 3; ++k) c[h][k] = C[k] - P[k];
+      const double reach = (sqrt(fmax(0.0, (double)S.r2[h])) +
+                            0x1.6p-10 * (rho + fabs(C[0] - g[0]) + fabs(C[1] - g[1]) + fabs(C[2] - g[2]))) *
+                           (1.0 + 0x1p-20);
+      Rh[h] = reach + delta + 0x1p-60;
+      cn[h] = sqrt(dot3(c[h], c[h]));
+      // P inside (or all but inside) the reach: every direction, and the "before P" argument is off
+      around[h] = real[h] && !(cn[h] > Rh[h] * 1.001 + 1e-4 * rho);
+    }
+    for (int face = 0; face < 6; ++face) {
+      int32_t *hdr = LL.hdr + (size_t)(li * 6 + face) * kTileHdrInts;
+      int m, ia, ib;
+      double sign;
+      light_face_axes(face, m, ia, ib, sign);
+      bool face_global = false, have = false;
+      double ext[4] = {1e300, -1e300, 1e300, -1e300};
+      for (int h = 0; h < 2; ++h) {
+        if (!real[h]) continue;
+        if (around[h]) {
+          face_global = true;
+          continue;
+        }
+        const double depth = sign * c[h][m];
+        if (depth > Rh[h] * (1.0 + 1e-9)) { // wholly in front of the face's plane through P
+          const CamD cam = light_face_frame(P, face);
+          double e[4];
+          if (!sphere_pixel_extent(cam, Rr + 1, Rr + 1, c[h], Rh[h], e, nullptr, 1e-3)) {
+            face_global = true;
+            continue;
+          }
+          ext[0] = fmin(ext[0], e[0]);
+          ext[1] = fmax(ext[1], e[1]);
+          ext[2] = fmin(ext[2], e[2]);
+          ext[3] = fmax(ext[3], e[3]);
+          have = true;
+        } else {
+          // cut by (or behind) the plane: relevant only if the disc reaches the face's directions,
+          // all within acos(1 / sqrt 3) = 0.95532 rad of the axis
+          const double ang = acos(fmax(-1.0, fmin(1.0, depth / cn[h])));
+          const double phi = asin(fmin(1.0, Rh[h] / cn[h]));
+          if (!(ang > 0.95532 + phi + 1e-6)) face_global = true;
+        }
+      }
+      if (face_global) {
+        if (lane == 0) {
+          const int slot = atomicAdd(&hdr[0], 1);
+          if (slot < kTileGlobalCap) hdr[8 + slot] = j;
+        }
+        continue;
+      }
+      if (!have) continue;
+      const int u0 = max(0, (int)floor(ext[0])), u1 = min(Rr - 1, (int)floor(ext[1]));
+      const int w0 = max(0, (int)floor(ext[2])), w1 = min(Rr - 1, (int)floor(ext[3]));
+      if (u0 > u1 || w0 > w1) continue; // seen from P through other faces only
+      const int nx = u1 - u0 + 1, n = nx * (w1 - w0 + 1);
+      const size_t cell0 = (size_t)(li * 6 + face) * cells_per_face;
+      for (int k = lane; k < n; k += 64) {
+        const size_t cell = cell0 + (size_t)(w0 + k / nx) * Rr + u0 + k % nx;
+        const int slot = atomicAdd(&LL.cnt[cell], 1);
+        if (slot < kLightListCap) LL.ids[cell * kLightListCap + slot] = j;
+      }
+    }
+  }
+}
+
+// the cell (over all listed lights and faces) of the shadow ray that starts at `o` towards the
+// sample point P of listed light li
+DEVINL int light_list_cell(const LightLists &LL, int li, f3 P, f3 o) {
+  const f3 v = o - P;
+  const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z);
+  int m = 0;
+  float dm = ax;
+  if (ay > dm) { m = 1; dm = ay; }
+  if (az > dm) { m = 2; dm = az; }
+  const float vm = (m == 0) ? v.x : (m == 1) ? v.y : v.z;
+  const float va = (m == 0) ? v.y : v.x;
+  const float vb = (m == 2) ? v.y : v.z;
+  const int face = 2 * m + ((vm < 0.f) ? 1 : 0);
+  const float hR = 0.5f * (float)LL.R;
+  const int cu = min(LL.R - 1, max(0, (int)floorf((va / dm + 1.f) * hR)));
+  const int cw = min(LL.R - 1, max(0, (int)floorf((vb / dm + 1.f) * hR)));
+  return ((li * 6 + face) * LL.R + cw) * LL.R + cu; // (NaN direction: cell 0 of some face; such a ray has tb = 0)
+}
+
+// Shadow rays of a wave through the light lists of light li: one distinct cell of its live rays at a
+// time (wave-uniform: the records come through the scalar cache like everywhere else), every live
+// ray tested against every list swept -- a ray's own cell holds all its candidates, the others'
+// cannot add a wrong one.  Returns false when some live ray cannot be served (its cell or face list
+// overflowed): the caller runs the group sweep for the wave, which is complete on its own.
+// n_tests: per lane, sphere tests executed while the ray was live.
+template <typename FetchE>
+DEVINL bool anyhit_sph_light_lists(const LightLists &LL, int cell, FetchE rece, int base, f3 o, f3 L, Any &a,
+                                   int &n_tests, int &swept) {
+  const v2f oxy = {o.x, o.y}, oz_ = {o.z, 0.f}, Lxy = {L.x, L.y}, Lz_ = {L.z, 0.f};
+  auto exact2 = [&](int k0, int k1) { // sorted pair records k0, k1: the reference arithmetic
+    const PairG R[2] = {rece(k0), rece(k1)};
+    v2f b[2], q[2];
+    pair2_any_pk(R, oxy, oz_, Lxy, Lz_, b, q);
+    const int m = max(max3i(__float_as_int(q[0].x), __float_as_int(q[0].y), __float_as_int(q[1].x)),
+                      __float_as_int(q[1].y));
+    if (!ANY_LANE_RARE(m >= 0)) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float t2;
+        if (sph_exact(comp(b[i], c), comp(q[i], c), a.tb, t2))
+          any_accept(a, base + 2 * (i ? k1 : k0) + c, t2); // a position in the sorted table
+      }
+  };
+  const int cells_per_face = LL.R * LL.R;
+  const ListPtr cnt = (ListPtr)(uintptr_t)LL.cnt;
+  unsigned long long done = 0;
+  for (;;) {
+    const unsigned long long todo = __builtin_amdgcn_ballot_w64(a.tb > 0.f) & ~done;
+    if (todo == 0) return true;
+    const int leader = __builtin_ctzll(todo);
+    const int c = __builtin_amdgcn_readlane(cell, leader);
+    const ListPtr hdr = (ListPtr)(uintptr_t)(LL.hdr + (size_t)(c / cells_per_face) * kTileHdrInts);
+    const int n_glob = hdr[0], n = cnt[c];
+    if (n_glob > kTileGlobalCap || n > kLightListCap || hdr[2] != 0) return false;
+    const SmemFetch<DevIdx4> glob{reinterpret_cast<const DevIdx4 *>(LL.hdr + (size_t)(c / cells_per_face) * kTileHdrInts + 8)};
+    const SmemFetch<DevIdx4> ids{reinterpret_cast<const DevIdx4 *>(LL.ids + (size_t)c * kLightListCap)};
+    auto batch = [&](const DevIdx4 &I) { // four pair records = 8 spheres
+      n_tests += (a.tb > 0.f) ? 8 : 0;
+      swept += 8;
+      exact2(I.v[0], I.v[1]);
+      exact2(I.v[2], I.v[3]);
+    };
+    for (int k = 0; k < n_glob; k += 4) { // (lists are read in whole batches of 4: spare slots hold
+      if (__builtin_amdgcn_ballot_w64(a.tb > 0.f) == 0) return true; //  valid records)
+      batch(glob(k >> 2));
+    }
+    for (int k = 0; k < n; k += 4) {
+      if (__builtin_amdgcn_ballot_w64(a.tb > 0.f) == 0) return true;
+      batch(ids(k >> 2));
+    }
+    done |= __builtin_amdgcn_ballot_w64(cell == c);
+  }
+}
+
 } // namespace esc

@@ -74,6 +74,34 @@ HDINL int band_tile_row(const RenderParams &p, int j) {
   return lr >> 2;
 }
 
+// Cube map around a light sample point P (rt_device.h LightLists).  Face f = 2 m + (negative ? 1 : 0),
+// m the axis of the largest |component| of a direction v (lowest index on ties); its other two
+// components over |v[m]|, in axis order, are the face coordinates (u, w) in [-1, 1]; cell = floor((u +
+// 1) R / 2), floor((w + 1) R / 2).  As a "camera": rays p(s, t) = A + s H + t V with H = 2 e_a, V = 2 e_b,
+// A = +-e_m - e_a - e_b, s = (u + 1) / 2, t = (w + 1) / 2, so that with W - 1 = H - 1 = R a "pixel
+// coordinate" is a continuous cell coordinate.
+HDINL void light_face_axes(int face, int &m, int &ia, int &ib, double &sign) {
+  m = face >> 1;
+  sign = (face & 1) ? -1.0 : 1.0;
+  ia = (m == 0) ? 1 : 0;
+  ib = (m == 2) ? 1 : 2;
+}
+HDINL CamD light_face_frame(const double P[3], int face) {
+  int m, ia, ib;
+  double sign;
+  light_face_axes(face, m, ia, ib, sign);
+  RenderParams q;
+  for (int k = 0; k < 3; ++k) {
+    q.origin[k] = 0.f;
+    q.horizontal[k] = (k == ia) ? 2.f : 0.f;
+    q.vertical[k] = (k == ib) ? 2.f : 0.f;
+    q.llc[k] = (k == m) ? (float)sign : ((k == ia || k == ib) ? -1.f : 0.f);
+  }
+  CamD c = cam_frame(q);
+  for (int k = 0; k < 3; ++k) c.o[k] = P[k];
+  return c;
+}
+
 // Pixel extents ext = {wlo, whi, hlo, hhi} (double, NOT clipped to the image, grown by what fp32
 // rounding can move a ray) outside which no primary ray's line passes within R of c (= C - o).
 // false: unbounded (the camera plane cuts the sphere) or nothing can be said.  depth (optional)
@@ -81,7 +109,7 @@ HDINL int band_tile_row(const RenderParams &p, int j) {
 // a sphere behind the camera cross the image point-mirrored -- a CONVEX HULL of several spheres'
 // extents is only meaningful when all of them lie on one side).
 HDINL bool sphere_pixel_extent(const CamD &cam, int W, int H, const double c[3], double R, double ext[4],
-                               double *depth = nullptr) {
+                               double *depth = nullptr, double pad_px = -1.0) {
   const double iR2 = 1.0 / (R * R);
   const double c1 = dot3(cam.b1, c), c2 = dot3(cam.b2, c), c3 = dot3(cam.b3, c);
   if (depth) *depth = c3;
@@ -93,8 +121,10 @@ HDINL bool sphere_pixel_extent(const CamD &cam, int W, int H, const double c[3],
   const double sa = (q13 - ds) / q33, sb = (q13 + ds) / q33;
   const double ta = (q23 - dt) / q33, tb = (q23 + dt) / q33;
   const double W1 = (double)(W - 1), H1 = (double)(H - 1);
-  const double pw = 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1;
-  const double ph = 1.0 + (cam.nb2 + cam.nb3) * cam.eps_p * 1.01 * H1;
+  // pad_px >= 0: the caller's own pad (light-space maps: the lookup is the library's, not the
+  // reference's pixel grid)
+  const double pw = pad_px >= 0.0 ? pad_px : 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1;
+  const double ph = pad_px >= 0.0 ? pad_px : 1.0 + (cam.nb2 + cam.nb3) * cam.eps_p * 1.01 * H1;
   const double big = 1e9;
   ext[0] = fmax(-big, fmin(big, fmin(sa, sb) * W1 - pw));
   ext[1] = fmax(-big, fmin(big, fmax(sa, sb) * W1 + pw));

@@ -254,7 +254,14 @@ enum {
    * reference arithmetic behind the lists, same image.  This flag (or $ESC_LISTS=0) keeps the
    * three-level sweep of round 2 for every tile -- the A/B switch and a cross-check in tests; tiles
    * whose lists overflow take that sweep anyway. */
-  ESC_RENDER_NO_TILE_LISTS = 32
+  ESC_RENDER_NO_TILE_LISTS = 32,
+  /* The same from the light's end: a light that offers one sample point this frame (a one-face
+   * light, or ESC_FACE_FIXED) has all its shadow rays on lines through that point, so the spheres a
+   * ray can reach are listed per direction cell of a cube map around the point, once per scene
+   * (csrc/rt_lists.h "Light lists"); a wavefront looks its rays' cells up and tests those lists with
+   * the reference arithmetic.  This flag (or $ESC_LLISTS=0) keeps the three-level group sweep for
+   * every shadow ray; rays the lists cannot serve take it anyway. */
+  ESC_RENDER_NO_LIGHT_LISTS = 64
 };
 
 typedef struct {
