@@ -79,6 +79,7 @@ struct esc_context {
   esc::DevTriPairPF *d_tri2_pf = nullptr;
   float shadow_center[3] = {0, 0, 0};
   float shadow_rho_max = 0.f;
+  float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0}; // grown scene box (light lists)
   int32_t *d_sph_mat = nullptr;
   esc::DevMat *d_mat = nullptr;
   esc::DevLight *d_lights = nullptr;
@@ -374,6 +375,15 @@ int commit(esc_context *ctx, const Staged &s) {
         rho += std::max(hi[a] - (double)g[a], (double)g[a] - lo[a]);
       }
       rho = 2.0 * rho + 1e-30;
+      // the box itself, grown by 5 % of its size and rounded outwards: the region the light lists'
+      // reach is computed for (rt_lists.h "Light lists"; every first shadow-ray origin is inside)
+      const double grow_by = 0.05 * ((hi[0] - lo[0]) + (hi[1] - lo[1]) + (hi[2] - lo[2])) + 1e-30;
+      for (int a = 0; a < 3; a++) {
+        ctx->scene_lo[a] = std::nextafterf((float)(lo[a] - grow_by), -__builtin_huge_valf());
+        ctx->scene_hi[a] = std::nextafterf((float)(hi[a] + grow_by), __builtin_huge_valf());
+      }
+    } else {
+      for (int a = 0; a < 3; a++) ctx->scene_lo[a] = ctx->scene_hi[a] = 0.f;
     }
   }
   // filter form of the triangle table for shadow rays (rt_brute.h "Triangle FILTERS"), in double,
@@ -1367,6 +1377,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.tri2_f = ctx->d_tri2_f;
   p.shadow_rho_max = ctx->shadow_rho_max;
   std::memcpy(p.shadow_center, ctx->shadow_center, 12);
+  std::memcpy(p.scene_lo, ctx->scene_lo, 12);
+  std::memcpy(p.scene_hi, ctx->scene_hi, 12);
   {
     static const bool env_off = [] {
       const char *e = std::getenv("ESC_FILTER");
@@ -1758,9 +1770,27 @@ void camera_params(const esc_camera *cam, int32_t W, int32_t H, esc::RenderParam
 
 int esc_tile_list_counts(esc_context *ctx, int32_t which, int32_t hdr[8], int32_t *counts,
                          size_t capacity) {
-  if (!ctx || !hdr || (which != 0 && which != 1)) {
+  if (!ctx || !hdr || which < 0 || which > 2) {
     set_error("esc_tile_list_counts: bad argument");
     return ESC_ERR_INVALID;
+  }
+  if (which == 2) { // the light lists: cells of every listed light and face
+    if (!ctx->ll_valid || !ctx->ll.hdr) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int Rr = ctx->ll.R, n_faces = ctx->ll.n_listed * 6;
+    int32_t glob_max = 0;
+    for (int f = 0; f < n_faces; f++) {
+      int32_t g = 0;
+      HIP_TRY(hipMemcpy(&g, ctx->ll.hdr + (size_t)f * esc::kTileHdrInts, 4, hipMemcpyDeviceToHost));
+      glob_max = std::max(glob_max, g);
+    }
+    const int32_t out[8] = {glob_max, 0, 0, Rr, n_faces * Rr, esc::kLightListCap, esc::kTileGlobalCap, 0};
+    std::memcpy(hdr, out, sizeof(out));
+    const size_t n_cells = (size_t)n_faces * Rr * Rr;
+    if (counts)
+      HIP_TRY(hipMemcpy(counts, ctx->ll.cnt, std::min(capacity, n_cells) * 4, hipMemcpyDeviceToHost));
+    return (int)n_cells;
   }
   const esc::TileLists &L = which ? ctx->tl : ctx->sl;
   const int n_groups = which ? ctx->list_key.n_tg : ctx->list_key.n_sg;

@@ -298,7 +298,10 @@ struct TileLists {
 // overflows or a ray starts outside the region the reach was computed for.
 // ---------------------------------------------------------------------------------------
 constexpr int kLightListMax = 4;    // lights (sample points) that get lists
-constexpr int kLightListRes = 128;  // cells per cube-face side
+#ifndef ESC_LL_RES
+#define ESC_LL_RES 128
+#endif
+constexpr int kLightListRes = ESC_LL_RES;  // cells per cube-face side
 constexpr int kLightListCap = 64;   // pair records per cell (a multiple of 4)
 struct LightLists {
   int32_t *hdr;  // [n_listed * 6][kTileHdrInts]: [0] face-global pair records, [2] off, [8..) their ids
@@ -474,6 +477,7 @@ struct RenderParams {
   const DevTriPairF *tri2_f; // filter form of tri for shadow rays (per scene), ceil(n_tri / 2)
   float shadow_rho_max;      // 1-norm radius around g inside which DevTriPairF's margins hold
   float shadow_center[3];    // g of DevSphPairF / DevTriPairF
+  float scene_lo[3], scene_hi[3]; // the scene's box, grown: shadow-ray origins the light lists serve
   int32_t use_filter;        // 0: every test runs the reference arithmetic (A/B switch, tests)
   const int32_t *sph_mat; // material index of sphere k (already offset by n_geom)
   const DevMat *mat;      // [n_geom + n_sphere_materials]

@@ -999,8 +999,10 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
               // hold every sphere a ray's line can reach -- unless a ray starts outside the region
               // the reach was computed for, or its cell overflowed: then the sweep below runs
               bool served = false;
+              const bool outside = !(so.x >= p.scene_lo[0] && so.x <= p.scene_hi[0] && so.y >= p.scene_lo[1] &&
+                                     so.y <= p.scene_hi[1] && so.z >= p.scene_lo[2] && so.z <= p.scene_hi[2]);
               if (p.ll.enabled && li < p.ll.n_listed && n_rec <= kSegGroupPairs &&
-                  __builtin_amdgcn_ballot_w64(aa[0].tb > 0.f && far) == 0) {
+                  __builtin_amdgcn_ballot_w64(aa[0].tb > 0.f && outside) == 0) {
                 const f3 Pl = ld3(p.light_points + 4 * p.ll.point[li]);
                 int n_tests = 0, sw = 0;
                 served = anyhit_sph_light_lists(

@@ -330,12 +330,12 @@ DEVINL void tri2_listed_primary(FetchF recf, FetchE rece, const int32_t *orig, i
 
 
 // ---------------------------------------------------------------------------------------
-// Light lists (rt_device.h LightLists).  For a shadow ray (O, L) towards the sample point P, |O - g|_1
-// <= rho_max (rays from further out take the sweep), rt_brute.h "Sphere GROUPS for shadow rays"
-// gives: sphere i not rejected at `disc < 0`  ==>  the ray's LINE passes within
-//     r_i (1+u) + 5.4 sqrt(u) |O - c_i| + 2^-74  <=  r_i (1+u) + 0x1.6p-10 (rho_max + |c_i - g|_1)
+// Light lists (rt_device.h LightLists).  For a shadow ray (O, L) towards the sample point P that
+// starts inside the (grown) scene box B -- rays from outside take the sweep -- rt_brute.h "Sphere
+// GROUPS for shadow rays" gives: sphere i not rejected at `disc < 0`  ==>  the ray's LINE passes within
+//     r_i (1+u) + 5.4 sqrt(u) |O - c_i| + 2^-74  <=  r_i (1+u) + 0x1.6p-10 W_i,  W_i = max over B's corners |x - c_i|
 // of c_i.  L = fl(normalize(fl(P - O))) is within 3u of the true direction, so the line also passes
-// within delta = 2^-20 (rho_max + |P - g|_1) of P; shifted by that much it runs through P itself
+// within delta = 2^-20 (|B|_1 + |P - g|_1) of P; shifted by that much it runs through P itself
 // and within R_i = (the reach above) + delta of c_i: the direction from P to the ray's origin lies in
 // the disc of angular radius asin(R_i / |c_i - P|) around c_i - P.  An accept also needs t2 < |P - O|
 // - eps, i.e. the sphere on the ray's side of P -- unless P is (nearly) inside the reach, and such
@@ -369,9 +369,12 @@ __global__ void __launch_bounds__(256) k_bin_light_pairs(const RenderParams p) {
       real[h] = S.r2[h] >= 0.f; // pad half: r2 = -inf
       const double C[3] = {S.cx[h], S.cy[h], S.cz[h]};
       for (int k = 0; k < 3; ++k) c[h][k] = C[k] - P[k];
-      const double reach = (sqrt(fmax(0.0, (double)S.r2[h])) +
-                            0x1.6p-10 * (rho + fabs(C[0] - g[0]) + fabs(C[1] - g[1]) + fabs(C[2] - g[2]))) *
-                           (1.0 + 0x1p-20);
+      double far2 = 0.0; // the farthest corner of the box of ray origins
+      for (int k = 0; k < 3; ++k) {
+        const double d = fmax(fabs(C[k] - (double)p.scene_lo[k]), fabs(C[k] - (double)p.scene_hi[k]));
+        far2 += d * d;
+      }
+      const double reach = (sqrt(fmax(0.0, (double)S.r2[h])) + 0x1.6p-10 * sqrt(far2)) * (1.0 + 0x1p-20);
       Rh[h] = reach + delta + 0x1p-60;
       cn[h] = sqrt(dot3(c[h], c[h]));
       // P inside (or all but inside) the reach: every direction, and the "before P" argument is off

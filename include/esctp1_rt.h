@@ -392,7 +392,9 @@ int esc_tile_band(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, i
                   const float normal[3], double kp);
 
 /* For inspection and tests: the tile lists the last frame of this context was rendered with
- * (which = 0 spheres, 1 triangles).  hdr receives {global primitives, cone entries, lists-off
+ * (which = 0 spheres, 1 triangles; 2 = the light lists of the shadow pass: one "tile" per direction
+ * cell, tiles_x = cells per face side, tile_rows = faces x cells per side, hdr[0] = the longest
+ * face-global list).  hdr receives {global primitives, cone entries, lists-off
  * flag, tiles_x, tile_rows, list capacity, global capacity, 0}; counts (may be NULL) the appended
  * primitive count of up to `capacity` tiles -- a count above the list capacity means that tile took
  * the three-level sweep.  Returns the number of tiles, 0 when the context holds no lists, or a

@@ -17,7 +17,7 @@ cam = esc.Camera.for_image(*esc.synthetic_view(), W, H)
 buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
 r.render_rows(cam, W, H, 0, H, out_f32=buf)
 r.synchronize()
-for which, name in ((0, "sphere groups"), (1, "triangle groups")):
+for which, name in ((0, "spheres"), (1, "triangles"), (2, "light-list cells (pair records)")):
     L = r.tile_lists(which)
     if L is None:
         print(cfg, name, ": no lists")
