@@ -86,7 +86,7 @@ struct esc_multi {
   std::vector<void *> out;
   void *gathered = nullptr, *frame = nullptr;
   size_t out_cap = 0, gathered_cap = 0, frame_cap = 0;
-  std::vector<hipEvent_t> t0, t1;
+  std::vector<hipEvent_t> t0, t1, t2; // render start / end, peer copy done
   bool have_scene = false;
 };
 
@@ -144,6 +144,7 @@ void esc_multi_destroy(esc_multi *m) {
     if (i < (int)m->out.size() && m->out[i] && i != 0) (void)hipFree(m->out[i]);
     if (i < (int)m->t0.size() && m->t0[i]) (void)hipEventDestroy(m->t0[i]);
     if (i < (int)m->t1.size() && m->t1[i]) (void)hipEventDestroy(m->t1[i]);
+    if (i < (int)m->t2.size() && m->t2[i]) (void)hipEventDestroy(m->t2[i]);
     if (i == 0) {
       if (m->gathered) (void)hipFree(m->gathered);
       if (m->frame) (void)hipFree(m->frame);
@@ -164,9 +165,14 @@ int esc_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_r
     set_error("esc_multi_create: no HIP device (this renderer has no CPU fallback)");
     return ESC_ERR_NO_DEVICE;
   }
-  if (n_devices > avail) {
-    set_error("esc_multi_create: n_devices exceeds the device count (one communicator rank per "
-              "device; esc_render_frame_multi shares devices between bands instead)");
+  // With RCCL every rank needs its own device (one communicator rank per device).  WITHOUT it
+  // (use_rccl == 0: peer copies) ranks may share devices -- device_ids may repeat, and with
+  // device_ids == NULL rank i takes device i % count: the whole n-rank path (partition, per-rank
+  // pitch and offsets, copies into the gathered blocks, assembly) then runs on however many GPUs
+  // there are.  That is how the 1-GPU test box exercises n = 2, 3, 8.
+  if (use_rccl && n_devices > avail) {
+    set_error("esc_multi_create: n_devices exceeds the device count (one RCCL rank per device; "
+              "use_rccl = 0 lets ranks share devices)");
     return ESC_ERR_INVALID;
   }
   esc_multi *m = new (std::nothrow) esc_multi();
@@ -174,9 +180,9 @@ int esc_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_r
   m->n = n_devices;
   m->use_rccl = use_rccl != 0;
   for (int i = 0; i < n_devices; i++) {
-    const int d = device_ids ? device_ids[i] : i;
-    if (d < 0 || d >= avail || std::count(m->devices.begin(), m->devices.end(), d)) {
-      set_error("esc_multi_create: device ids must be distinct and in range");
+    const int d = device_ids ? device_ids[i] : (use_rccl ? i : i % avail);
+    if (d < 0 || d >= avail || (use_rccl && std::count(m->devices.begin(), m->devices.end(), d))) {
+      set_error("esc_multi_create: device ids must be in range, and distinct with RCCL");
       delete m;
       return ESC_ERR_INVALID;
     }
@@ -186,10 +192,12 @@ int esc_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_r
   m->out.assign((size_t)n_devices, nullptr);
   m->t0.assign((size_t)n_devices, nullptr);
   m->t1.assign((size_t)n_devices, nullptr);
+  m->t2.assign((size_t)n_devices, nullptr);
   for (int i = 0; i < n_devices; i++) {
     int rc = esc_context_create(m->devices[i], &m->ctx[i]);
     if (rc == ESC_OK) {
-      if (hipEventCreate(&m->t0[i]) != hipSuccess || hipEventCreate(&m->t1[i]) != hipSuccess) {
+      if (hipEventCreate(&m->t0[i]) != hipSuccess || hipEventCreate(&m->t1[i]) != hipSuccess ||
+          hipEventCreate(&m->t2[i]) != hipSuccess) {
         set_error("esc_multi_create: hipEventCreate failed");
         rc = ESC_ERR_HIP;
       }
@@ -304,11 +312,15 @@ int esc_multi_render(esc_multi *m, const esc_camera *cam, int32_t W, int32_t H,
         if (!bytes[(size_t)i]) continue;
         hipStream_t sti = (hipStream_t)esc_context_stream(m->ctx[i]);
         M_HIP(hipSetDevice(m->devices[i]));
-        M_HIP(hipMemcpyPeerAsync((char *)m->gathered + (size_t)i * pitch, m->devices[0], m->out[i],
-                                 m->devices[i], bytes[(size_t)i], sti));
-        M_HIP(hipEventRecord(m->t1[i], sti));
+        if (m->devices[i] == m->devices[0]) // ranks sharing a device: a plain device-to-device copy
+          M_HIP(hipMemcpyAsync((char *)m->gathered + (size_t)i * pitch, m->out[i], bytes[(size_t)i],
+                               hipMemcpyDeviceToDevice, sti));
+        else
+          M_HIP(hipMemcpyPeerAsync((char *)m->gathered + (size_t)i * pitch, m->devices[0], m->out[i],
+                                   m->devices[i], bytes[(size_t)i], sti));
+        M_HIP(hipEventRecord(m->t2[i], sti)); // (t1 keeps bracketing the render: ms_per_device)
         M_HIP(hipSetDevice(m->devices[0]));
-        M_HIP(hipStreamWaitEvent(st0, m->t1[i], 0));
+        M_HIP(hipStreamWaitEvent(st0, m->t2[i], 0));
       }
     }
   }
@@ -323,7 +335,7 @@ int esc_multi_render(esc_multi *m, const esc_camera *cam, int32_t W, int32_t H,
     M_HIP(hipStreamSynchronize((hipStream_t)esc_context_stream(m->ctx[i])));
     if (ms_per_device) {
       ms_per_device[i] = 0.f;
-      if (i == 0 || m->use_rccl || n == 1) M_HIP(hipEventElapsedTime(&ms_per_device[i], m->t0[i], m->t1[i]));
+      M_HIP(hipEventElapsedTime(&ms_per_device[i], m->t0[i], m->t1[i]));
     }
   }
   if (d_frame) *d_frame = m->frame;

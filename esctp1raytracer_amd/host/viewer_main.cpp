@@ -10,13 +10,19 @@
 //                                                            they selected are retired)
 //   --bvh         render through the acceleration structure (ESC_STAGE_BVH): what the flag was
 //                 meant to do in the reference (main.cpp:566-570,792-800), same image as without
-//   --ispc        render through the `trace` drop-in symbol on flatten_scene_ispc-style arrays
+//   --ispc        render through the `trace` drop-in symbol on flatten_scene_ispc-style arrays, in
+//                 (geometry, face) order: the scalar path's image bit for bit.  NOT the reference's
+//                 centroid-x sort (flatten_iscp.cpp:110) -- parity with the reference's own --ispc
+//                 image is unpinned either way (its run is undefined before it reaches trace)
+//   --ispc-sorted the same with that sort (the reference's primitive order: ties and, with two or
+//                 more lights, first occluders follow it)
 //   -w W,H        window size.  NOTE: in the reference this flag writes into `look`
 //                 (main.cpp:515-529) and the window stays 1024x768; here
 //                 it does what its help text says.
-//   --gpus N      8-row strips over N devices from this one process: gathered over RCCL when every
-//                 band has its own GPU, else bands share devices and strips go straight to the host
-//   --no-rccl     keep --gpus on the host-copy path
+//   --gpus N      8-row strips over N bands from this one process; bands share the GPUs there are and
+//                 their strips go straight to the host (esc_render_frame_multi)
+//   --rccl        with --gpus: one GPU per band, strips gathered to device 0 over RCCL instead
+//                 (opt-in: its exchange has not run on more than one device yet)
 //   --scene c2|c3|c4|c5[:n]   synthetic BASELINE.json workload instead of -m
 //   --shadows 0|1  --seed S  --face K   light-face choice: hashed (default) or fixed K
 //   --dump-f32 path           raw fp32 RGB framebuffer, (h*W+w)*3 order, h = 0 bottom
@@ -57,7 +63,7 @@ void parse_floats(const char *flag, char *arg, float *out, int n, const char *er
 
 int main(int argc, char *argv[]) {
   std::string modelname, outputname, dumpname, synthetic;
-  bool threaded = false, flat = false, ispc = false, no_rccl = false;
+  bool threaded = false, flat = false, ispc = false, use_rccl = false, ispc_sorted = false;
   int debug = 1; // INFO, debug.h:3
   float eye[3] = {0, 1, 3}, look[3] = {0, 1, 0}; // main.cpp:426
   int W = 1024, H = 768;                         // main.cpp:427
@@ -86,7 +92,9 @@ int main(int argc, char *argv[]) {
       continue;
     }
     if (a == "--gpus") { if (!next) die("--gpus needs N"); gpus = std::atoi(next); arg++; continue; }
-    if (a == "--no-rccl") { no_rccl = true; continue; }
+    if (a == "--rccl") { use_rccl = true; continue; }
+    if (a == "--no-rccl") { use_rccl = false; continue; } // (the default; kept for old command lines)
+    if (a == "--ispc-sorted") { ispc = ispc_sorted = true; continue; }
     if (a == "--scene") { if (!next) die("--scene needs a config"); synthetic = next; arg++; continue; }
     if (a == "--shadows") { if (!next) die("--shadows needs 0|1"); shadows = std::atoi(next); arg++; continue; }
     if (a == "--seed") { if (!next) die("--seed needs S"); seed = std::strtoull(next, nullptr, 0); arg++; continue; }
@@ -163,7 +171,10 @@ int main(int argc, char *argv[]) {
     // sort permutes primitive indices, which changes equal-t ties and -- with two or more lights
     // -- the first occluder occlusion() reports in index order, whose t2 the next light's shadow
     // ray starts from (quirk S3).  Unsorted, --ispc writes the scalar path's image bit for bit.
-    check(esc_flatten_ispc(scene, /*sort_by_centroid_x=*/0, &fs), "flatten_scene_ispc");
+    // --ispc-sorted keeps the reference's sort: its primitive order, hence its ties and first
+    // occluders; no reference fixture pins that image (the reference's own --ispc run is undefined
+    // behaviour before it reaches trace), so it is "parity unpinned".
+    check(esc_flatten_ispc(scene, /*sort_by_centroid_x=*/ispc_sorted ? 1 : 0, &fs), "flatten_scene_ispc");
     ispc_cam icam;
     esc_new_ispc_cam(&icam, eye, look, vup, vfov, aspect);
     int32_t nt = 0, nl = 0, nlt = 0;
@@ -178,16 +189,18 @@ int main(int argc, char *argv[]) {
   } else if (ctx) {
     check(esc_render_frame_host(ctx, &cam, W, H, &opts, image.data(), nullptr), "render");
   } else {
-    // N devices from this one process.  With a GPU per band the strips are gathered to device 0
-    // over RCCL (esc_render_frame_multi_rccl); more bands than GPUs (or no RCCL on this host, or
-    // --no-rccl) fall back to the band-sharing path that copies strips straight to the host.
+    // N devices from this one process.  Default: the band-sharing path that copies every band's
+    // strips straight to the host (esc_render_frame_multi; runs with any number of GPUs, verified on
+    // the GPU box).  --rccl: a GPU per band, strips gathered to device 0 over RCCL
+    // (esc_render_frame_multi_rccl) -- opt-in, because its n > 1 exchange (grouped ncclSend /
+    // ncclRecv) has not run on more than one device yet.
     std::vector<float> ms((size_t)gpus, 0.f);
     int rc = ESC_ERR_RCCL;
-    if (!no_rccl && esc_rccl_available())
+    if (use_rccl && esc_rccl_available())
       rc = esc_render_frame_multi_rccl(scene, &cam, W, H, &opts, gpus, image.data(), nullptr,
                                        ms.data());
     if (rc != ESC_OK) {
-      if (debug >= 2) std::cerr << " RCCL path not used: " << esc_last_error() << std::endl;
+      if (use_rccl) std::cerr << " RCCL path not used: " << esc_last_error() << std::endl;
       check(esc_render_frame_multi(scene, &cam, W, H, &opts, gpus, image.data(), nullptr, ms.data()),
             "render");
     }

@@ -436,10 +436,16 @@ int esc_render_frame_multi(const esc_scene *scene, const esc_camera *cam, int32_
  * esc_assemble_strips lays the frame out on the first device.  RCCL is bound at run time
  * (dlopen of librccl.so; $ESC_RCCL_LIB overrides), so the library itself does not link it.
  *   use_rccl = 0 replaces the exchange by hipMemcpyPeerAsync (same layout; for hosts without RCCL).
- *   n_devices must not exceed the device count (one communicator rank per device). */
+ *   With RCCL n_devices must not exceed the device count and the ids must be distinct (one
+ *   communicator rank per device).  Without it ranks may SHARE devices: device_ids may repeat, and
+ *   with device_ids == NULL rank i takes device i % count -- the n-rank partition, offsets, copies
+ *   and assembly then run on however many GPUs there are (how a 1-GPU box tests n = 2, 3, 8).
+ *   STATE OF VERIFICATION: the n > 1 path without RCCL runs in the GPU tests (ranks sharing one
+ *   device); the grouped ncclSend / ncclRecv exchange has so far only run with n = 1, where it
+ *   moves nothing. */
 typedef struct esc_multi esc_multi;
 int esc_rccl_available(void); /* 1 / 0 (esc_last_error says why not) */
-int esc_multi_create(int32_t n_devices, const int32_t *device_ids /* NULL = 0..n-1 */,
+int esc_multi_create(int32_t n_devices, const int32_t *device_ids /* NULL = 0..n-1 (RCCL) / i % count */,
                      int32_t use_rccl, esc_multi **out);
 void esc_multi_destroy(esc_multi *m);
 int esc_multi_upload_scene(esc_multi *m, const esc_scene *scene); /* replicated on every device */
@@ -450,7 +456,10 @@ int esc_multi_upload_scene(esc_multi *m, const esc_scene *scene); /* replicated 
 int esc_multi_render(esc_multi *m, const esc_camera *cam, int32_t W, int32_t H,
                      const esc_render_options *opts, int32_t gather_u8, float *image,
                      uint8_t *rgb8, void **d_frame, float *ms_per_device /* [n] or NULL */);
-/* create + upload + render + destroy in one call (the shape of esc_render_frame_multi) */
+/* create + upload + render + destroy in one call (the shape of esc_render_frame_multi).
+ * NOTE: every call creates the contexts, uploads the scene to every device AND initialises an RCCL
+ * communicator (ncclCommInitAll: tens to hundreds of milliseconds), then tears all of it down.
+ * Meant for a viewer's single frame; a caller that renders in a loop keeps an esc_multi. */
 int esc_render_frame_multi_rccl(const esc_scene *scene, const esc_camera *cam, int32_t W, int32_t H,
                                 const esc_render_options *opts, int32_t n_devices, float *image,
                                 uint8_t *rgb8, float *ms_per_device /* [n_devices] or NULL */);
