@@ -14,9 +14,9 @@ RCCL and laid out as one frame there; total work is fixed, so scaling is "strong
 
 Rank 0 prints ONE JSON line.  `value` = rays of all ranks / wall time (max over ranks) in
 Mrays/s; rays = primary (W*H) + shadow (hit pixels x lights), counted by the kernel itself.
-The timed path sweeps the linear primitive table through three levels of spatial groups
-(bounding spheres / normal cones in front of the same conservative filters: DESIGN.md 3.6-3.7) and
-`config.workload` says so; `linear` is the same frame with every (ray, primitive) pair visited in
+The timed path is a CULLED sweep -- per-tile and per-light-cell primitive lists from projected
+conservative bounds, spatial groups behind them (csrc/rt_lists.h) -- in front of
+the same filters and reference arithmetic, and `config.workload` says so; `linear` is the same frame with every (ray, primitive) pair visited in
 the reference's index order (ESC_RENDER_INDEX_ORDER) -- BASELINE's "brute-force intersect" point.
 `roofline` is the HBM view north_star asks for (algorithmic bytes / measured kernel time vs
 8 TB/s); `valu` holds what actually bounds these kernels, from the committed rocprofv3 counters
@@ -59,7 +59,7 @@ def source_stamp():
 
 
 def committed_profile(config):
-    """profiles/current.json: per-frame PMC numbers of the SHIPPED kernels, grouped and linear paths
+    """profiles/current.json: per-frame PMC numbers of the SHIPPED kernels, culled and linear paths
     (tools/summarize_prof.py writes it, stamped with source_stamp()).  Returns None when it belongs to
     other sources -- a stale counter must never be passed off as this run's."""
     path = os.path.join(ROOT, "profiles", "current.json")
@@ -108,12 +108,17 @@ def parse():
     ap.add_argument("--stage", default="auto", choices=["auto", "smem", "lds", "bvh"],
                     help="auto/smem/lds are brute force (BASELINE's algorithm, the default); bvh "
                          "makes the opt-in acceleration structure the measured path")
-    ap.add_argument("--path", default="grouped", choices=["grouped", "linear"],
-                    help="grouped (default): the table is swept through its spatial groups; linear: "
+    ap.add_argument("--path", default="culled", choices=["culled", "linear"],
+                    help="culled (default): tile lists / light lists / spatial groups decide which "
+                         "primitives a ray's filters and reference arithmetic run on; linear: "
                          "ESC_RENDER_INDEX_ORDER, every pair in the reference's index order, is the "
                          "TIMED path (what tools/profile.sh wraps for the `linear` counters)")
     ap.add_argument("--linear-steps", type=int, default=-1,
                     help="frames of the `linear` leg (default: min(steps, 5); 0 = skip)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="timed steps call esc_render_strips (parameter block + kernel launches per "
+                         "frame) instead of replaying a recorded frame (esc_frame_record: one "
+                         "hipGraphLaunch per frame)")
     ap.add_argument("--no-accel", action="store_true",
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
     ap.add_argument("--profile-run", action="store_true",
@@ -338,6 +343,19 @@ def main():
         renderers.append(rb)
         streams.append(stb)
 
+    # the frame of each (renderer, buffer) pair recorded once (HIP graph): a timed step is then ONE
+    # host call; --no-graph keeps the plain entry
+    recorded = [None] * n_buf
+    if not a.no_graph:
+        for b in range(n_buf):
+            with torch.cuda.stream(streams[b % len(streams)]):
+                recorded[b] = renderers[b % len(renderers)].record_strips(
+                    cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
+                    out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows, stage=stage,
+                    flags=path_flags)
+        for rr in renderers:
+            rr.synchronize()
+
     events = []
     # every event a step needs exists before the timed region (at N = 8 a rank's share of the
     # frame is ~0.1 ms: the host side of a step must not be the slower half)
@@ -359,9 +377,12 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
             e0.record(ss)
-            rr.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
-                             out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows,
-                             stage=stage, flags=path_flags)
+            if recorded[b] is not None:
+                recorded[b].launch()
+            else:
+                rr.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
+                                 out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows,
+                                 stage=stage, flags=path_flags)
             e1.record(ss)
             if timed:
                 events.append((e0, e1))
@@ -430,7 +451,7 @@ def main():
     linear = None
     anyhit_index_order = None
     n_lin = a.linear_steps if a.linear_steps >= 0 else min(a.steps, 5)
-    if world == 1 and a.stage != "bvh" and not a.profile_run and a.path == "grouped" and n_lin > 0:
+    if world == 1 and a.stage != "bvh" and not a.profile_run and a.path == "culled" and n_lin > 0:
         lin_ev = []
         for i in range(n_lin + 1):
             with torch.cuda.stream(st):
@@ -476,6 +497,48 @@ def main():
     fence()
     frame_latency_ms = (time.perf_counter() - t1) * 1e3
     r.synchronize()
+
+    # (after the last use of the recorded frames: rendering another band rebuilds the tile lists they
+    # were recorded with)
+    # host side of a frame: K frames enqueued back to back with no event and no synchronisation in
+    # between -- the queue never fills at this depth, so the loop's wall time is host work only.
+    # For the whole frame and for rank 0's share of an 8-rank frame (where it matters: that share is
+    # a few tens of microseconds of GPU work).
+    host = None
+    if world == 1 and a.stage != "bvh":
+        host = {"what": "host microseconds per frame, K frames enqueued without waiting: `plain` = "
+                        "esc_render_strips (parameter block + one launch per kernel), `recorded` = "
+                        "esc_frame_launch (one hipGraphLaunch); through the Python binding",
+                "timed_steps_use": "plain" if a.no_graph else "recorded"}
+        share = torch.zeros(multigpu.max_local_rows(H, 8, S) * W * 3, dtype=ch_dtype, device=dev)
+        for label, fs, stride, out in (("whole_frame", 0, 1, local[0]), ("rank_0_of_8", 0, 8, share)):
+            kw = dict(out_f32=None if use_u8 else out, out_u8=out if use_u8 else None, strip_rows=S,
+                      shadows=shadows, stage=stage, flags=path_flags)
+            n_rep = max(a.steps, 20)
+            with torch.cuda.stream(st):
+                rec = r.record_strips(cam, W, H, fs, stride, **kw)
+                r.synchronize()
+                th = time.perf_counter()
+                for _ in range(n_rep):
+                    rec.launch()
+                t_rec = (time.perf_counter() - th) / n_rep * 1e6
+                r.synchronize()
+                th = time.perf_counter()
+                for _ in range(n_rep):
+                    r.render_strips(cam, W, H, fs, stride, **kw)
+                t_plain = (time.perf_counter() - th) / n_rep * 1e6
+                r.synchronize()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(st)
+                for _ in range(n_rep):
+                    rec.launch()
+                ev1.record(st)
+                r.synchronize()
+                rec.close()
+            host[label] = {"plain_us_per_frame": t_plain, "recorded_us_per_frame": t_rec,
+                           "gpu_us_per_frame_back_to_back": ev0.elapsed_time(ev1) / n_rep * 1e3}
+        host["host_us_per_frame"] = host["whole_frame"]["plain_us_per_frame" if a.no_graph
+                                                        else "recorded_us_per_frame"]
 
     # N=1, for information only (the headline stays one frame at a time so that kernel.avg_ms is an
     # undisturbed duration): the same K frames with two in flight on two streams, which fills the
@@ -534,11 +597,15 @@ def main():
                       "(ESC_RENDER_INDEX_ORDER): every (ray, primitive) pair is decided by the "
                       "reference arithmetic or by a proven conservative filter in front of it -- "
                       "BASELINE's brute-force intersect",
-            "grouped": ("3-level group culling over the linear primitive table: the proven filters "
-                        "run on bounding spheres / normal cones of spatial groups of 8, 64-128 and "
-                        "512-1,024 primitives first, members of opened groups go through the same "
-                        "filters and the reference arithmetic (DESIGN.md 3.6-3.7); tables under 64 "
-                        "primitives are swept linearly"),
+            "culled": ("culled sweep of the primitive table (not brute force): per camera, every "
+                       "32x4-pixel tile lists the primitives its primary rays can touch; per one-point "
+                       "light, every direction cell lists the sphere pairs a shadow ray can reach "
+                       "(projected bounds grown by the reference's rounding reach, csrc/rt_lists.h); "
+                       "listed primitives go through the proven filters and the reference arithmetic; "
+                       "what the lists cannot serve -- overflowing tiles / cells, triangle shadow "
+                       "rays, multi-point lights -- sweeps 3 levels of spatial groups (8 / 64-128 / "
+                       "512-1,024 primitives: DESIGN.md 3.6-3.7); tables under 64 primitives are "
+                       "swept linearly"),
         }["bvh" if a.stage == "bvh" else a.path]
         out = {
             "metric": "Mrays/sec + frame ms, 3840x2160 / 10k spheres, at 1/2/4/8 MI355X",
@@ -595,6 +662,8 @@ def main():
                                          "WRITE_SIZE passes, fetch doubled per the gfx950 note; the "
                                          "kernels are VALU-bound, not HBM-bound: see `valu`"},
         }
+        if host is not None:
+            out["host"] = host
         if kernel_split is not None:
             out["kernel_split"] = kernel_split
         # what bounds the kernels: committed rocprofv3 counters of the shipped sources (stamped)

@@ -18,7 +18,7 @@ from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_BVH
                     ESC_STAGE_SMEM, EscError,
                     check)
 
-__all__ = ["Scene", "Camera", "Renderer", "FlatScene", "MultiRenderer", "render_multi", "render_multi_rccl", "rccl_available", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
+__all__ = ["Scene", "Camera", "Renderer", "RecordedFrame", "FlatScene", "MultiRenderer", "render_multi", "render_multi_rccl", "rccl_available", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
            "EscError", "ESC_FACE_FIXED", "ESC_FACE_HASH", "ESC_STAGE_AUTO", "ESC_STAGE_SMEM",
            "ESC_STAGE_LDS", "ESC_STAGE_BVH", "ESC_RENDER_EXACT_ONLY", "ESC_RENDER_TIME_KERNELS", "ESC_RENDER_INDEX_ORDER", "ESC_RENDER_SHADE_QUEUE",
            "ESC_RENDER_SHADE_FUSED", "ESC_RENDER_NO_TILE_LISTS", "ESC_RENDER_NO_LIGHT_LISTS", "version"]
@@ -313,6 +313,20 @@ class Renderer:
                                           self._dev_ptr(out_f32, n * 4), self._dev_ptr(out_u8, n)))
         return rows
 
+    def record_strips(self, camera, W, H, first_strip, strip_stride, out_f32=None, out_u8=None, *,
+                      strip_rows=8, shadows=True, face_mode=ESC_FACE_FIXED, fixed_face=0, seed=0,
+                      stage=ESC_STAGE_AUTO, px=0, flags=0):
+        """esc_frame_record: the launches of this render_strips call captured into a HIP graph.
+        Returns a RecordedFrame; .launch() replays it with one host call."""
+        rows = strip_local_rows(H, strip_rows, first_strip, strip_stride)
+        n = rows * W * 3
+        o = _options(shadows, face_mode, fixed_face, seed, stage, px, flags)
+        h = C.c_void_p()
+        check(self._lib.esc_frame_record(self._h, C.byref(camera.c), W, H, strip_rows, first_strip,
+                                         strip_stride, C.byref(o), self._dev_ptr(out_f32, n * 4),
+                                         self._dev_ptr(out_u8, n), C.byref(h)))
+        return RecordedFrame(self._lib, h, (out_f32, out_u8))
+
     def assemble_strips(self, gathered, n_ranks, rank_pitch_bytes, W, H, frame, *, strip_rows=8,
                         bytes_per_pixel=12):
         """gathered: n_ranks blocks of local rows (block r at r*rank_pitch_bytes) -> frame."""
@@ -374,6 +388,27 @@ class Renderer:
         check(self._lib.esc_tile_list_counts(self._h, which, hdr, cnt.ctypes.data_as(C.POINTER(C.c_int32)), n))
         return {"global": hdr[0], "cones": hdr[1], "off": hdr[2], "tiles_x": hdr[3], "tile_rows": hdr[4],
                 "cap": hdr[5], "global_cap": hdr[6], "counts": cnt.reshape(hdr[4], hdr[3])}
+
+
+class RecordedFrame:
+    """esc_frame: one frame's launches as a HIP graph on its renderer's stream"""
+
+    def __init__(self, lib, handle, keep):
+        self._lib, self._h, self._keep = lib, handle, keep  # the output buffers must outlive the graph
+        self._launch = lib.esc_frame_launch
+
+    def launch(self):
+        rc = self._launch(self._h)
+        if rc:
+            check(rc)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.esc_frame_destroy(h)
+
+    def __del__(self):
+        self.close()
 
 
 def strip_local_rows(H, strip_rows, first_strip, strip_stride):

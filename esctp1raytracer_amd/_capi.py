@@ -140,6 +140,11 @@ SIGNATURES = {
                                   C.c_int32, C.POINTER(esc_render_options), _P, _P]),
     "esc_render_strips": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.POINTER(esc_render_options), _P, _P]),
+    "esc_frame_record": (C.c_int, [_P, C.POINTER(esc_camera), C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.POINTER(esc_render_options), _P, _P,
+                                   C.POINTER(C.c_void_p)]),
+    "esc_frame_launch": (C.c_int, [_P]),
+    "esc_frame_destroy": (None, [_P]),
     "esc_strip_local_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "esc_assemble_strips": (C.c_int, [_P, _P, C.c_int32, C.c_size_t, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, _P]),

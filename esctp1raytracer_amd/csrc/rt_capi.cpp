@@ -88,6 +88,11 @@ struct esc_context {
   int n_tri = 0, n_sph = 0, n_lights = 0, n_geom = 0;
   int min_light_faces = 0; // smallest face count among the lights (bounds ESC_FACE_FIXED)
   bool have_scene = false;
+  // bumped whenever per-camera / per-scene device state is rebuilt (prepare kernels, tile and light
+  // lists, the tree, scratch buffers): a recorded frame (esc_frame) replays launches that read that
+  // state and is only valid for the epoch it was recorded in
+  uint64_t epoch = 0;
+  bool capturing = false; // inside esc_frame_record's stream capture: nothing may rebuild
   bool prepared = false;
   float prepared_origin[3] = {0, 0, 0};
   int32_t *d_hits = nullptr; // k_primary -> k_shade hand-over: 3 planes (idx, t, v) of hits_cap dwords
@@ -840,6 +845,7 @@ int commit(esc_context *ctx, const Staged &s) {
     ctx->min_light_faces = (i == 0) ? s.lights[i].n_faces
                                     : std::min(ctx->min_light_faces, (int)s.lights[i].n_faces);
   ctx->have_scene = true;
+  ctx->epoch++;
   ctx->prepared = false;
   ctx->lists_valid = false;
   ctx->list_ids_stale = true;
@@ -964,6 +970,7 @@ int build_accel_device(esc_context *ctx, const float origin[3]) {
       std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->accel_ob = a.ob;
   ctx->accel_valid = true;
+  ctx->epoch++;
   return ESC_OK;
 }
 
@@ -1407,6 +1414,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       ctx->hits_cap = 0;
       HIP_TRY(hipMalloc((void **)&ctx->d_hits, need * 3 * sizeof(int32_t)));
       ctx->hits_cap = need;
+      ctx->epoch++;
     }
     p.hits.idx = ctx->d_hits;
     p.hits.t = reinterpret_cast<float *>(ctx->d_hits + ctx->hits_cap);
@@ -1422,6 +1430,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     }
     std::memcpy(ctx->prepared_origin, cam->origin, 12);
     ctx->prepared = true;
+    ctx->epoch++;
   }
   // ---- tile lists of the primary pass (rt_lists.h): per camera and band, cached while both stand
   {
@@ -1486,6 +1495,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
         }
         ctx->list_key = key;
         ctx->lists_valid = true;
+        ctx->epoch++;
       }
     }
   }
@@ -1539,6 +1549,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
         ctx->ll_face_mode = opts->face_mode;
         ctx->ll_fixed_face = opts->fixed_face;
         ctx->ll_valid = true;
+        ctx->epoch++;
       }
     }
   }
@@ -1565,6 +1576,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       }
       std::memcpy(ctx->accel_prepared_origin, cam->origin, 12);
       ctx->accel_prepared = true;
+      ctx->epoch++;
     }
     p.bvh_tri = esc::BvhRef{ctx->d_bvh_tri_nodes, ctx->d_bvh_tri_blocks, ctx->d_bvh_tri_blocks_p,
                             ctx->d_bvh_tri_order, ctx->accel_info.tri_root, 0};
@@ -1700,6 +1712,89 @@ int esc_render_strips(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   if (rows < 0) return rows;
   return render_local_rows(ctx, cam, W, H, first_strip * strip_rows, rows, strip_rows,
                            strip_stride * strip_rows, opts, d_rgb_f32, d_rgb_u8);
+}
+
+struct esc_frame {
+  esc_context *ctx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  uint64_t epoch = 0;
+};
+
+int esc_frame_record(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H, int32_t strip_rows,
+                     int32_t first_strip, int32_t strip_stride, const esc_render_options *opts,
+                     float *d_rgb_f32, uint8_t *d_rgb_u8, esc_frame **out) {
+  if (!ctx || !cam || !opts || !out) {
+    set_error("esc_frame_record: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (opts->flags & ESC_RENDER_TIME_KERNELS) {
+    set_error("esc_frame_record: ESC_RENDER_TIME_KERNELS records events between the kernels and "
+              "cannot be part of a recorded frame");
+    return ESC_ERR_INVALID;
+  }
+  // one plain frame first: it builds everything the frame's kernels read (per-camera tables, the
+  // lists, scratch buffers) -- none of that may happen inside a stream capture
+  int rc = esc_render_strips(ctx, cam, W, H, strip_rows, first_strip, strip_stride, opts, d_rgb_f32,
+                             d_rgb_u8);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const uint64_t epoch = ctx->epoch;
+  esc_frame *f = new (std::nothrow) esc_frame();
+  if (!f) return ESC_ERR_NOMEM;
+  f->ctx = ctx;
+  hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    set_error(std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+    delete f;
+    return ESC_ERR_HIP;
+  }
+  ctx->capturing = true;
+  rc = esc_render_strips(ctx, cam, W, H, strip_rows, first_strip, strip_stride, opts, d_rgb_f32,
+                         d_rgb_u8);
+  ctx->capturing = false;
+  e = hipStreamEndCapture(ctx->stream, &f->graph);
+  if (rc == ESC_OK && (e != hipSuccess || ctx->epoch != epoch)) {
+    set_error(e != hipSuccess ? std::string("hipStreamEndCapture: ") + hipGetErrorString(e)
+                              : std::string("esc_frame_record: device state was rebuilt during the capture"));
+    rc = ESC_ERR_HIP;
+  }
+  if (rc == ESC_OK) {
+    e = hipGraphInstantiate(&f->exec, f->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+      set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+      rc = ESC_ERR_HIP;
+    }
+  }
+  if (rc != ESC_OK) {
+    if (f->graph) (void)hipGraphDestroy(f->graph);
+    delete f;
+    return rc;
+  }
+  f->epoch = epoch;
+  *out = f;
+  return ESC_OK;
+}
+
+int esc_frame_launch(esc_frame *f) {
+  if (!f || !f->exec) {
+    set_error("esc_frame_launch: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  if (f->ctx->epoch != f->epoch) {
+    set_error("esc_frame_launch: the context rendered another camera, size or scene since this "
+              "frame was recorded (its kernels would read rebuilt tables): record it again");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipGraphLaunch(f->exec, f->ctx->stream));
+  return ESC_OK;
+}
+
+void esc_frame_destroy(esc_frame *f) {
+  if (!f) return;
+  if (f->exec) (void)hipGraphExecDestroy(f->exec);
+  if (f->graph) (void)hipGraphDestroy(f->graph);
+  delete f;
 }
 
 int esc_assemble_strips(esc_context *ctx, const void *d_gathered, int32_t n_ranks,

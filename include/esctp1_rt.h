@@ -327,6 +327,23 @@ int esc_render_strips(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
 /* number of rows the call above renders (>= 0), or ESC_ERR_INVALID */
 int esc_strip_local_rows(int32_t H, int32_t strip_rows, int32_t first_strip,
                          int32_t strip_stride);
+/* A recorded frame: the launches of one esc_render_strips call captured into a HIP graph, replayed
+ * with ONE host call per frame.  At 8 GPUs a rank's share of a 4K frame is a few tens of
+ * microseconds of GPU work, the same order as the host side of a plain frame (parameter block, two
+ * or more kernel launches); a recorded frame costs one hipGraphLaunch.  esc_frame_record renders one
+ * plain frame first (it builds everything the kernels read), then captures the second.  A recorded
+ * frame replays exactly those launches -- same camera, band, options and output buffers -- and is
+ * only valid while the context's per-camera / per-scene device state stands: esc_frame_launch
+ * returns ESC_ERR_INVALID once the context has rendered another camera, size or scene, or had a
+ * scene uploaded (record again).  Counters accumulate as for plain frames.
+ * ESC_RENDER_TIME_KERNELS cannot be recorded. */
+typedef struct esc_frame esc_frame;
+int esc_frame_record(esc_context *ctx, const esc_camera *cam, int32_t W, int32_t H, int32_t strip_rows,
+                     int32_t first_strip, int32_t strip_stride, const esc_render_options *opts,
+                     float *d_rgb_f32, uint8_t *d_rgb_u8, esc_frame **out);
+int esc_frame_launch(esc_frame *frame); /* asynchronous, on the context's stream */
+void esc_frame_destroy(esc_frame *frame);
+
 /* After a gather of N such buffers to one device (block r at d_gathered + r*rank_pitch_bytes):
  * writes the H x W frame in (h*W+w) order.  bytes_per_pixel = 12 (fp32 RGB) or 3 (u8 RGB).
  * Asynchronous on the context's stream. */

@@ -344,3 +344,56 @@ def test_lists_equal_sweep_full_size(esc, renderer, config, W, H):
     assert frac_over < 0.2, f"{frac_over:.2%} of the tiles overflow"
     if config != "c5":
         assert st[2] is not None
+
+
+@pytest.mark.parametrize("stage", ["auto", "bvh"])
+def test_recorded_frames_replay_the_same_frame(esc, renderer, stage):
+    """esc_frame_record / esc_frame_launch: one frame's launches as a HIP graph.  Replays write the
+    frame the plain entry writes (and count the same rays); once the context has rendered another
+    camera the recorded frame is refused (its kernels would read rebuilt per-camera tables), and a
+    new recording works again.  Rank 1 of 3 as well as the whole frame."""
+    import torch
+    st = {"auto": esc.ESC_STAGE_AUTO, "bvh": esc.ESC_STAGE_BVH}[stage]
+    sc, d = synthetic_dict(esc, "c3", 500)
+    eye, look = esc.synthetic_view()
+    W, H = 200, 96
+    renderer.upload(sc)
+    cam = esc.Camera.for_image(eye, look, W, H)
+    ref = ol.oracle_render(d, eye, look, W, H, threads=8)
+    for first, stride in ((0, 1), (1, 3)):
+        rows = esc.strip_local_rows(H, 8, first, stride)
+        plain = torch.zeros(rows * W * 3, dtype=torch.float32, device="cuda:0")
+        renderer.render_strips(cam, W, H, first, stride, out_f32=plain, stage=st)
+        renderer.synchronize()
+        if stride == 1:
+            assert_bit_equal(plain.cpu().numpy().reshape(H, W, 3), ref, "plain frame")
+        out = torch.zeros_like(plain)
+        u8 = torch.zeros(rows * W * 3, dtype=torch.uint8, device="cuda:0")
+        rec = renderer.record_strips(cam, W, H, first, stride, out_f32=out, out_u8=u8, stage=st)
+        renderer.reset_counters()
+        renderer.render_strips(cam, W, H, first, stride, out_f32=plain, stage=st)
+        one = renderer.counters()
+        renderer.reset_counters()
+        for _ in range(3):
+            out.zero_()
+            rec.launch()
+            renderer.synchronize()
+            assert bool(torch.equal(out.view(torch.int32), plain.view(torch.int32)))
+        three = renderer.counters()
+        for k in ("primary_rays", "hit_pixels", "shadow_rays"):
+            assert three[k] == 3 * one[k]
+        assert np.array_equal(u8.cpu().numpy(), ol.oracle_quantise(plain.cpu().numpy()))
+        # another camera on the same context: the recording is stale and says so
+        renderer.render_strips(esc.Camera.for_image((1, 3, 6), look, W, H), W, H, first, stride,
+                               out_f32=plain, stage=st)
+        with pytest.raises(esc.EscError):
+            rec.launch()
+        rec.close()
+        rec = renderer.record_strips(cam, W, H, first, stride, out_f32=out, stage=st)
+        out.zero_()
+        rec.launch()
+        renderer.synchronize()
+        renderer.render_strips(cam, W, H, first, stride, out_f32=plain, stage=st)
+        renderer.synchronize()
+        assert bool(torch.equal(out.view(torch.int32), plain.view(torch.int32)))
+        rec.close()

@@ -509,8 +509,8 @@ def test_committed_profile_was_measured_on_these_sources():
     cur = json.load(open(os.path.join(root, "profiles", "current.json")))
     assert cur["source_stamp"] == ns["source_stamp"](), \
         "csrc/ or the Makefile changed after the last tools/profile.sh + summarize_prof.py --current run"
-    # both sweeps are profiled: the default (grouped) path and the linear brute-force path
-    assert set(cur["paths"]) == {"grouped", "linear"}
+    # both sweeps are profiled: the default (culled) path and the linear brute-force path
+    assert set(cur["paths"]) == {"culled", "linear"}
     for path in cur["paths"].values():
         assert path["hbm_bytes_per_frame"] > 0
         for kern in path["kernels"].values():

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Profiles bench.py's default run (c4, 1 GPU) on the GPU box, for BOTH sweeps: grouped (the default
+# Profiles bench.py's default run (c4, 1 GPU) on the GPU box, for BOTH sweeps: culled (the default
 # path) and linear (--path linear = ESC_RENDER_INDEX_ORDER).  Separate passes: kernel trace + stats
 # of the default command (CPU baseline skipped: it launches no kernels), then PMC counters on their
 # own (never mixed with trace domains), without the BVH leg.
@@ -10,7 +10,7 @@ CFG=${2:-c4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-for P in grouped linear; do
+for P in culled linear; do
   OUT=$R/gpurun_out/prof_$TAG/$P
   mkdir -p $OUT
   ACC=""; [ $P = linear ] && ACC="--no-accel"

@@ -7,7 +7,7 @@ tools/profile.sh or tools/prof_bvh.sh) into the small files kept under profiles/
                        with bench.py's source_stamp() -- bench.py refuses it when the stamp differs
 
 usage: python tools/summarize_prof.py <gpurun_out/prof_X> <profiles/rNN_X> [--current c4]
-With --current the source holds one sub-directory per path (grouped/, linear/: tools/profile.sh) and
+With --current the source holds one sub-directory per path (culled/, linear/: tools/profile.sh) and
 profiles/current.json gets, per path, the HBM bytes per frame and every SQ counter per kernel class
 (k_primary, k_shade = all shading kernels, k_frame) summed per frame.
 """
@@ -97,7 +97,7 @@ else:
     exec(src_txt[start:end], ns)
     cur = {"source_stamp": ns["source_stamp"](), "config": config,
            "source": os.path.relpath(dst, root), "paths": {}}
-    for path in ("grouped", "linear"):
+    for path in ("culled", "linear"):
         if not os.path.isdir(os.path.join(src, path)):
             continue
         out, _ = condense(os.path.join(src, path), os.path.join(dst, path))
