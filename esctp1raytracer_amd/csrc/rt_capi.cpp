@@ -457,6 +457,7 @@ int commit(esc_context *ctx, const Staged &s) {
       const double km = r2 - c2 + 0x1p-16 * (c2 + std::fabs(r2)) + 0x1p-120;
       float kf = (float)km;
       if ((double)kf < km) kf = std::nextafterf(kf, __builtin_huge_valf());
+      if (kf != kf) kf = __builtin_huge_valf(); // non-finite input: "always a candidate", not the negative default NaN
       F.cx[h] = c[0];
       F.cy[h] = c[1];
       F.cz[h] = c[2];
@@ -508,6 +509,7 @@ int commit(esc_context *ctx, const Staged &s) {
       const double km = R2 - c2 + 0x1p-16 * (c2 + R2) + 0x1p-120;
       float kf = (float)km;
       if ((double)kf < km) kf = std::nextafterf(kf, __builtin_huge_valf());
+      if (kf != kf) kf = __builtin_huge_valf(); // (as above)
       F.cx[h] = c[0];
       F.cy[h] = c[1];
       F.cz[h] = c[2];
@@ -623,7 +625,10 @@ int commit(esc_context *ctx, const Staged &s) {
       F.cx[h] = c[0];
       F.cy[h] = c[1];
       F.cz[h] = c[2];
-      F.km[h] = kf; // NaN stays NaN: its bit pattern reads as a candidate
+      // a non-finite centre or radius gives km = NaN, and the x86 default NaN is NEGATIVE: read as
+      // an int32 it would say "never a candidate"; +inf says "always one" (the exact code decides)
+      if (kf != kf) kf = __builtin_huge_valf();
+      F.km[h] = kf;
     };
     for (size_t k = 0; k < sg_sorted.size(); k++) {
       const esc::DevSph &q = sg_sorted[k];

@@ -91,13 +91,16 @@ OriginBounds origin_bounds(const std::vector<DevTri> &tri, const std::vector<Dev
     // More than one light point: quirk S3 starts the NEXT light's shadow ray at
     // camera + dir * (t_occ - eps), t_occ = the previous light's occluder distance along ITS shadow
     // ray (main.cpp:757 with the t occlusion() left behind) -- a point on the primary ray that can
-    // lie past the hit surface and outside the scene box.  t_occ < that shadow ray's length <= the
-    // diagonal of (scene + lights + camera), so every such origin is within `diag` of the camera.
-    ob.ball = diag;
+    // lie past the hit surface and outside the scene box.  Light 2's origin o_2 has t_occ < light 1's
+    // shadow-ray length <= the diagonal of (scene + lights + camera): within `diag` of the camera.
+    // Light k's ray can be as long as |P_(k-1) - cam| + |cam - o_(k-1)|, so o_k lies within (k - 1) diag
+    // of the camera: the ball takes the number of light POINTS (>= lights) less one.
+    ob.ball_mult = (double)(light_points_xyz0.size() / 4 - 1);
+    ob.ball = ob.ball_mult * diag;
     for (int a = 0; a < 3; a++) ob.cam[a] = origin[a];
     for (int a = 0; a < 3; a++) {
-      ob.lo[a] = std::min(ob.lo[a], (double)origin[a] - diag);
-      ob.hi[a] = std::max(ob.hi[a], (double)origin[a] + diag);
+      ob.lo[a] = std::min(ob.lo[a], (double)origin[a] - ob.ball);
+      ob.hi[a] = std::max(ob.hi[a], (double)origin[a] + ob.ball);
     }
     diag = 0;
     for (int a = 0; a < 3; a++) diag += (ob.hi[a] - ob.lo[a]) * (ob.hi[a] - ob.lo[a]);
@@ -519,9 +522,19 @@ void group_order_points(const std::vector<float> &xyz, int run, int big, int hug
         if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
       const size_t runs = (n + (size_t)run - 1) / (size_t)run;
       const size_t left = (runs / 2) * (size_t)run; // 0 < left < n since runs >= 2
+      // a TOTAL order also for non-finite coordinates (a NaN vertex gives a NaN centroid; `<` on
+      // NaNs is not a strict weak ordering, which nth_element requires): keys are the fp32 bit
+      // patterns mapped monotonically to unsigned integers, NaNs after +inf; ties by index
+      auto key = [&](int32_t i) {
+        uint32_t u;
+        const float c = xyz[3 * (size_t)i + ax];
+        std::memcpy(&u, &c, 4);
+        if (c != c) return 0xffffffffu;                      // NaN: last
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // -x ... -0 +0 ... +x, ascending
+      };
       std::nth_element(idx, idx + left, idx + n, [&](int32_t a, int32_t b) {
-        const float ca = xyz[3 * (size_t)a + ax], cb = xyz[3 * (size_t)b + ax];
-        return ca < cb || (ca == cb && a < b);
+        const uint32_t ka = key(a), kb = key(b);
+        return ka < kb || (ka == kb && a < b);
       });
       go(xyz, small, big, huge, idx, left);
       go(xyz, small, big, huge, idx + left, n - left);
@@ -545,7 +558,7 @@ void group_order(const std::vector<DevTri> &tri, int run, int big, int huge,
                  std::vector<int32_t> &order) {
   std::vector<float> xyz(3 * tri.size());
   for (size_t i = 0; i < tri.size(); i++)
-    for (int a = 0; a < 3; a++) // the centroid; non-finite coordinates sort somewhere, harmlessly
+    for (int a = 0; a < 3; a++) // the centroid (non-finite ones sort last: group_order_points' keys)
       xyz[3 * i + a] = tri[i].v0[a] + (tri[i].e1[a] + tri[i].e2[a]) * (1.f / 3.f);
   group_order_points(xyz, run, big, huge, order);
 }

@@ -21,15 +21,16 @@ struct PrimBox {
 struct OriginBounds {
   double lo[3], hi[3];
   double ball = 0.0;
+  double ball_mult = 0.0;    // ball = ball_mult x (diagonal of scene + lights + camera): light points - 1
   double cam[3] = {0, 0, 0}; // the camera the bounds were built for
   // may a frame with the camera at p use pads computed for these bounds?  (a camera that moved by
-  // d sees a scene diagonal at most d longer, so its ball is at most ball + d)
+  // d sees a scene diagonal at most d longer, so its ball is at most ball + ball_mult d)
   bool contains(const float p[3]) const {
     double r = 0.0;
     if (ball > 0.0) {
       double d2 = 0.0;
       for (int a = 0; a < 3; a++) d2 += ((double)p[a] - cam[a]) * ((double)p[a] - cam[a]);
-      r = ball + __builtin_sqrt(d2);
+      r = ball + ball_mult * __builtin_sqrt(d2);
     }
     for (int a = 0; a < 3; a++)
       if (!(p[a] - r >= lo[a] && p[a] + r <= hi[a])) return false;

@@ -792,9 +792,43 @@ def test_native_multi_gpu_n_ranks_sharing_one_device(esc, renderer, n):
         m.close()
 
 
+def _oracle_scene_in_flat_order(flat):
+    """The oracle's scene with the triangles in the order of a flattened scene's triangles[] (one
+    geometry per triangle, its material and normals as the flat triangle carries them) and the
+    lights in the order of lights[]: what `trace` must render for these arrays.  One-face lights only
+    (a light geometry has to stay one geometry for quirk S2 / the light count)."""
+    tris = [flat.triangles[i] for i in range(flat.num_triangles)]
+    geoms = []
+    for t in tris:
+        v = np.array([[t.vertices[k][c] for c in range(3)] for k in range(3)], np.float32)
+        g = {"vertex": v, "face_index": np.array([[0, 1, 2]]),
+             "material": ol.material13(ka=list(t.ka), kd=list(t.kd), ks=list(t.ks), ke=list(t.ke), Ns=t.Ns)}
+        if t.has_normals:
+            g["normals"] = np.array([[t.normals[k][c] for c in range(3)] for k in range(3)], np.float32)
+        geoms.append(g)
+    d = ol.scene_dict(geoms)
+    order = []
+    for L in range(flat.num_lights):
+        lt = flat.lights[L]
+        assert lt.num_light_faces == 1
+        face = flat.light_triangles[lt.light_faces[0]]
+        want = [[face.vertices[k][c] for c in range(3)] for k in range(3)]
+        pos = [i for i, t in enumerate(tris)
+               if t.is_light and [[t.vertices[k][c] for c in range(3)] for k in range(3)] == want]
+        assert len(pos) == 1
+        order.append(pos[0])
+    assert sorted(order) == sorted(d["light_sources"])
+    d["light_sources"] = order  # the light LOOP order is the scene's, not the sort's (quirk S3)
+    return d
+
+
 def test_trace_drop_in(esc, renderer):
-    """The ispc::trace symbol on FlatScene arrays == the scene path, with and without the
-    reference's centroid-x sort (in this one-light scene the sort only permutes equal-t ties)."""
+    """The ispc::trace symbol on FlatScene arrays (trace.ispc:86-92 / main.cpp:619-624).  In (geometry,
+    face) order it is the scene path's image.  With the reference's centroid-x sort
+    (flatten_iscp.cpp:14-21,110) the primitive order changes -- equal-t ties and, with two lights,
+    the first occluder whose t2 moves the next light's ray (quirk S3) follow it -- so the sorted
+    arrays are rendered through the ORACLE in that same order and must match bit for bit: scene
+    `two` (two lights, per-vertex normals) and the Cornell box with its light cut to one triangle."""
     d = ol.load_dump("CornellBox-Original")
     sc = ol.scene_to_product(d)
     W, H = 128, 96
@@ -804,9 +838,6 @@ def test_trace_drop_in(esc, renderer):
     assert flat.num_triangles == 36 and flat.num_lights == 1 and flat.num_light_triangles == 2
     img = esc.trace(W, H, (0, 1, 2), (0, 1, 0), (0, 1, 0), 60.0, aspect, flat)
     assert_bit_equal(img, ref, "trace()")
-    flat_sorted = sc.flatten_ispc(sort_by_centroid_x=True)
-    img2 = esc.trace(W, H, (0, 1, 2), (0, 1, 0), (0, 1, 0), 60.0, aspect, flat_sorted)
-    assert np.allclose(img2, ref, atol=0, rtol=0) or (bits(img2) != bits(ref)).mean() < 0.01
     import os
     os.environ["ESC_TRACE_STAGE"] = "bvh"  # the seam's only way to opt into the tree
     try:
@@ -814,6 +845,25 @@ def test_trace_drop_in(esc, renderer):
     finally:
         del os.environ["ESC_TRACE_STAGE"]
     assert_bit_equal(img3, ref, "trace() through the BVH")
+    # ---- the reference's sort, pinned through the oracle in the permuted order
+    cornell1 = ol.load_dump("CornellBox-Original")
+    lg = cornell1["geometry"][cornell1["light_sources"][0]]
+    lg["face_index"] = lg["face_index"][:1]  # one face: the light sample is deterministic (S2 / S8)
+    lg["vertex"] = lg["vertex"][:3]
+    cornell1 = ol.scene_dict(cornell1["geometry"])
+    for name, dd, eye in (("two", ol.load_dump("two"), (0, 1, 3)), ("cornell, 1-face light", cornell1, (0, 1, 2))):
+        scd = ol.scene_to_product(dd)
+        unsorted = scd.flatten_ispc(sort_by_centroid_x=False)
+        srt = scd.flatten_ispc(sort_by_centroid_x=True)
+        order_u = [tuple(unsorted.triangles[i].vertices[0]) for i in range(unsorted.num_triangles)]
+        order_s = [tuple(srt.triangles[i].vertices[0]) for i in range(srt.num_triangles)]
+        assert sorted(order_u) == sorted(order_s) and order_u != order_s, name + ": the sort permutes"
+        base = ol.oracle_render(dd, eye, (0, 1, 0), W, H)
+        assert_bit_equal(esc.trace(W, H, eye, (0, 1, 0), (0, 1, 0), 60.0, aspect, unsorted), base,
+                         f"trace()/{name}/unsorted")
+        want = ol.oracle_render(_oracle_scene_in_flat_order(srt), eye, (0, 1, 0), W, H)
+        got = esc.trace(W, H, eye, (0, 1, 0), (0, 1, 0), 60.0, aspect, srt)
+        assert_bit_equal(got, want, f"trace()/{name}/sorted by centroid x")
 
 
 def test_empty_and_missing(esc, renderer):
@@ -1024,6 +1074,42 @@ def test_bvh_second_light_origin_outside_the_scene_box(esc, renderer):
     for stage in (esc.ESC_STAGE_AUTO, esc.ESC_STAGE_BVH):
         gpu, u8, _ = render_both(esc, renderer, d, eye, look, W, H, stage=stage)
         assert_bit_equal(gpu, ref, f"S3 far origin/stage{stage}")
+    assert ref.sum() > 0
+
+
+def test_bvh_third_light_origin_two_diagonals_out(esc, renderer):
+    """Quirk S3 with THREE lights: light 3's shadow ray starts at camera + dir * t where
+    t was left by light 2's ray, which itself started far outside the scene and is therefore up to
+    two scene diagonals long: OriginBounds' ball is (light points - 1) diagonals.  Light A far away
+    with its occluder next to it pushes light B's origins out; light B on the opposite far side with
+    ITS occluder next to it pushes light C's origins further still; spheres sit out there, on the
+    way to light C.  Brute force (lists, sweep) and the BVH stage against the oracle."""
+    rng = np.random.default_rng(33)
+    floor = np.array([[-6, 0, 4], [6, 0, 4], [6, 0, -6], [-6, 0, 4], [6, 0, -6], [-6, 0, -6]], np.float32)
+    lA = np.array([[-0.5, 30, -40], [0.5, 30, -40], [0, 30, -41]], np.float32)
+    lB = np.array([[-0.5, 40, 60], [0.5, 40, 60], [0, 40, 61]], np.float32)
+    lC = np.array([[8, -3, 2], [8.4, -3, 2], [8, -2.6, 2.2]], np.float32)
+    geoms = [{"vertex": floor, "face_index": np.arange(6).reshape(2, 3), "material": ol.WHITE}]
+    for lt, m in ((lA, ol.LIGHT_A), (lB, ol.LIGHT_B), (lC, ol.LIGHT_A)):
+        geoms.append({"vertex": lt, "face_index": np.array([[0, 1, 2]]), "material": m})
+    big = np.array([[0.0, 26.0, -35.0, 6.0], [0.0, 36.0, 54.0, 7.0]])  # next to A and next to B
+    n = 200
+    out = np.concatenate([rng.uniform(-12, 12, (n, 1)), rng.uniform(-60, -1, (n, 1)),
+                          rng.uniform(-80, 20, (n, 1)), rng.uniform(0.3, 2.5, (n, 1))], axis=1)
+    sph = np.concatenate([big, out]).astype(np.float32)
+    mats = np.stack([ol.material13(ka=m, kd=m) for m in rng.uniform(0.2, 0.9, (len(sph), 3))])
+    d = ol.scene_dict(geoms, sph, mats)
+    assert len(d["light_sources"]) == 3
+    eye, look = (0.0, 1.0, 3.0), (0.0, 0.0, 0.0)
+    W, H = 224, 128
+    ref, rc = ol.oracle_render(d, eye, look, W, H, threads=8, return_counters=True)
+    undo_s3 = ol.oracle_render(d, eye, look, W, H, threads=8, quirks=ol.ORC_QUIRK_S1)
+    assert (bits(ref) != bits(undo_s3)).sum() > 1000, "the scene does not exercise quirk S3"
+    for stage, flags in ((esc.ESC_STAGE_AUTO, 0),
+                         (esc.ESC_STAGE_AUTO, esc.ESC_RENDER_NO_TILE_LISTS | esc.ESC_RENDER_NO_LIGHT_LISTS),
+                         (esc.ESC_STAGE_BVH, 0)):
+        gpu, u8, _ = render_both(esc, renderer, d, eye, look, W, H, stage=stage, flags=flags)
+        assert_bit_equal(gpu, ref, f"S3 three lights/stage{stage}/flags{flags}")
     assert ref.sum() > 0
 
 
