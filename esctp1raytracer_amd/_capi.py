@@ -34,6 +34,7 @@ ESC_RENDER_SHADE_QUEUE = 8
 ESC_RENDER_SHADE_FUSED = 16
 ESC_RENDER_NO_TILE_LISTS = 32
 ESC_RENDER_NO_LIGHT_LISTS = 64
+ESC_RENDER_TWO_KERNELS = 128
 
 
 class EscError(RuntimeError):

@@ -37,7 +37,7 @@ extern "C" int esc_launch_bin_light(const esc::LightBins *g, const float *light_
                                     const esc::PrimBoxDev *sph_boxes, int n_sph,
                                     hipStream_t stream);
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px,
-                                 hipStream_t stream, hipEvent_t between);
+                                 hipStream_t stream, hipEvent_t between, int two_kernels);
 extern "C" int esc_launch_shade_queue(const esc::RenderParams *p, int li, int last, const int *segs,
                                       int n_segs, uint32_t *ctl, int n_wg, hipStream_t stream);
 extern "C" int esc_launch_primary_only(const esc::RenderParams *p, int px, hipStream_t stream);
@@ -1654,7 +1654,12 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     if (rc) return rc;
     e = 0;
   } else {
-    e = esc_launch_render(&p, stage, px, ctx->stream, timed ? ctx->ev[1] : nullptr);
+    static const bool env_two = [] {
+      const char *v = std::getenv("ESC_FRAME");
+      return v && std::strcmp(v, "2") == 0;
+    }();
+    e = esc_launch_render(&p, stage, px, ctx->stream, timed ? ctx->ev[1] : nullptr,
+                          (env_two || (opts->flags & ESC_RENDER_TWO_KERNELS)) ? 1 : 0);
   }
   if (timed && !e) {
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));

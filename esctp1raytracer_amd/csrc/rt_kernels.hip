@@ -602,29 +602,11 @@ DEVINL Tile<1> tile_again(const RenderParams &p) {
 // them (small scenes, ESC_RENDER_INDEX_ORDER, ESC_RENDER_EXACT_ONLY) is its own instantiation so
 // that the linear loops keep their registers (with both in one kernel the linear triangle loop of
 // c5 went from 427 to 507 ms).
-template <int STAGE, typename V, int NV, bool GRP = false>
-__global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
-  constexpr int PX = NV * lanes_of<V>::n; // pixels per work-item
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
-  const Tile<PX> T(p);
-  const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly;
-  const bool row_ok = (lr < p.n_local_rows) && (h < p.H);
-
-  int w[PX];
-  f3 dir[PX];
-  Hit hit[PX];
-#pragma unroll
-  for (int q = 0; q < PX; ++q) {
-    w[q] = T.w0 + T.lx0 + 16 * q;
-    dir[q] = primary_dir(p, w[q], h);
-    hit[q].t = FLT_MAX; // main.cpp:715
-    hit[q].v = 0.f;
-    hit[q].idx = -1;
-  }
-
-  // ---- main.cpp:722 closest hit over every primitive
-  V3<V> dv[NV];
-  pack3<V, NV>(dir, dv);
+// main.cpp:722 for the PX pixels of every lane: the closest hit over every primitive, through the
+// tile lists, the group sweeps or the linear loops (k_primary and the fused k_frame share it)
+template <int STAGE, typename V, int NV, bool GRP, int PX>
+DEVINL void primary_closest(const RenderParams &p, const Tile<PX> &T, const V3<V> (&dv)[NV], Hit (&hit)[PX],
+                            unsigned char *lds_raw) {
   // this wave's 32 x 4 pixel tile in the band (rt_device.h TileLists); a wave wholly outside the
   // band has nothing to test
   const int tile_x = (T.w0 >> 5) + (T.wave & 1), tile_y = (T.lr0 >> 2) + (T.wave >> 1);
@@ -715,6 +697,33 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
     }
   }
 
+}
+
+template <int STAGE, typename V, int NV, bool GRP = false>
+__global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
+  constexpr int PX = NV * lanes_of<V>::n; // pixels per work-item
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
+  const Tile<PX> T(p);
+  const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly;
+  const bool row_ok = (lr < p.n_local_rows) && (h < p.H);
+
+  int w[PX];
+  f3 dir[PX];
+  Hit hit[PX];
+#pragma unroll
+  for (int q = 0; q < PX; ++q) {
+    w[q] = T.w0 + T.lx0 + 16 * q;
+    dir[q] = primary_dir(p, w[q], h);
+    hit[q].t = FLT_MAX; // main.cpp:715
+    hit[q].v = 0.f;
+    hit[q].idx = -1;
+  }
+
+  // ---- main.cpp:722 closest hit over every primitive
+  V3<V> dv[NV];
+  pack3<V, NV>(dir, dv);
+  primary_closest<STAGE, V, NV, GRP, PX>(p, T, dv, hit, lds_raw);
+
   // ---- hand-over: idx for every pixel, t (and v when normals exist) for hit pixels; plane
   // stores, band-local pixel order
 #pragma unroll
@@ -735,6 +744,186 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
 // than 6 waves per SIMD leave (36 B of scratch per lane otherwise), so that variant is built for 5
 // and scenes without triangle groups keep the leaner kernel.
 constexpr int kListServed = 0x40000000; // RepackLds::n_open: this ray's sphere phase ran on light lists
+// ---------------------------------------------------------------------------------------
+// The shadow pass of ONE light for the 256 rays of a workgroup, primitives through the scalar cache
+// (main.cpp:772 occlusion(), wave-uniform loops): used by k_shade<SMEM> and by the fused k_frame.
+// In: every thread's ray (ro, rL, a0.tb; tb = 0: no ray).  Out: a0.kocc / a0.tocc (the occluder in
+// (triangles, spheres) order and its t2, quirk S3), what the sweep was (for the counters) and the
+// per-pixel shading state, which is parked in LDS while the sweeps run so that it holds no VGPRs
+// across them.  All 256 threads must call it (barriers inside).
+// ---------------------------------------------------------------------------------------
+template <bool TGRP>
+DEVINL void shadow_sweep_smem(const RenderParams &p, RepackLds &R, int tid, int wave, int lane, int li, f3 ro,
+                              f3 &rL, Any (&a)[1], f3 &N, float &r, float &g, float &b, float &t, int &mi,
+                              int &grp_open, bool &tri_groups, bool &sph_groups, int &n_swept) {
+  typedef float V;
+  constexpr int NV = 1;
+  // ---- segments of the primitive list, undecided rays re-packed in between
+  // (the LAST light sweeps the spheres by decreasing solid angle when the host built that
+  // order: its occluder is never read again -- rt_device.h sph2_ord)
+  const bool ord = (li == p.n_lights - 1) && p.sph2_ord != nullptr;
+  const DevSphPair *sweep_e = ord ? p.sph2_ord : p.sph2;
+  const DevSphPairF *sweep_f = ord ? p.sph2_f_ord : p.sph2_f;
+    R.ox[tid] = ro.x; R.oy[tid] = ro.y; R.oz[tid] = ro.z;
+  R.lx[tid] = rL.x; R.ly[tid] = rL.y; R.lz[tid] = rL.z;
+  R.tb[tid] = a[0].tb;
+  R.kocc[tid] = -1;
+  R.tocc[tid] = 0.f;
+  R.n_open[tid] = 0;
+  R.keep[0][tid] = N.x; R.keep[1][tid] = N.y; R.keep[2][tid] = N.z;
+  R.keep[3][tid] = r; R.keep[4][tid] = g; R.keep[5][tid] = b;
+  R.keep[6][tid] = t; R.keep[7][tid] = __int_as_float(mi);
+  // Occluded rays mostly meet their occluder early in the list, so re-packing pays at
+  // the beginning and not later: segment lengths double (256, 256, 512, 1024, ...
+  // triangles; 512, 512, 1024, ... pair records), which keeps the barriers few.
+  // the last light sweeps the sphere GROUPS when the host built them (rt_device.h SphGroups):
+  // k0 then counts pair records of the sorted table, 4 per group, segments whole steps
+  // Lights before the last sweep the groups too, in "first occluder" mode (rt_brute.h Any:
+  // every group visited, the accepted primitive with the lowest original index kept) --
+  // as long as the whole table is one segment, which it is below 2^20 records.
+  const bool last_light = li == p.n_lights - 1;
+  const bool grp = p.use_filter && p.sg.n_grp > 0 &&
+                   (last_light || p.sg.n_grp * (kSphGroup / 2) <= kSegGroupPairs);
+  const int n_rec = grp ? p.sg.n_grp * (kSphGroup / 2) : (p.n_sph + 1) >> 1;
+  // ... and the triangle GROUPS (rt_device.h TriGroups): k0 counts sorted slots, 8 per group
+  const bool tgrp = TGRP && p.use_filter && p.tg.n_grp > 0 &&
+                    (last_light || p.tg.n_grp * kTriGroup <= kSegGroupPairs);
+  const int n_tri_sweep = tgrp ? p.tg.n_grp * kTriGroup : p.n_tri;
+  int k0 = 0, seg = tgrp ? kSegGroupPairs : kSegTris; // triangles first (index order)
+  bool in_tris = p.n_tri > 0;
+  const int seg_sph = grp ? kSegGroupPairs : kSegSphPairs;
+  if (!in_tris) seg = seg_sph;
+  for (int sg = 0;; ++sg) {
+    if (in_tris && k0 >= n_tri_sweep) {
+      in_tris = false;
+      k0 = 0;
+      seg = seg_sph;
+      sg = 0;
+    }
+    if (!in_tris && k0 >= n_rec) break;
+    const int n_here = min(seg, (in_tris ? n_tri_sweep : n_rec) - k0);
+    const int n_live = repack_rays(R, tid);
+    if (n_live == 0) break; // workgroup-uniform
+    if (wave * 64 < n_live) { // otherwise this wave sits the segment out
+      const int slot = wave * 64 + lane;
+      const int rr = (slot < n_live) ? (int)R.list[slot] : -1;
+      const int rs = (rr >= 0) ? rr : tid;
+      Any aa[1];
+      aa[0].tb = (rr >= 0) ? R.tb[rs] : 0.f;
+      aa[0].tocc = 0.f;
+      aa[0].kocc = -1;
+      aa[0].orig = nullptr;
+      aa[0].orig_bias = aa[0].orig_add = 0;
+      const f3 so = mk(R.ox[rs], R.oy[rs], R.oz[rs]);
+      const f3 sL = mk(R.lx[rs], R.ly[rs], R.lz[rs]);
+      if (TGRP && in_tris && tgrp) {
+        bool far;
+        const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
+        const RayF rs = make_ray_filter(so, sL, p.shadow_center);
+        int n_open = 0;
+        if (!last_light) aa[0].orig = reinterpret_cast<const int32_t *>(p.tg.orig); // bias, add 0
+        // k0 sorted slots in = k0 / 8 groups = k0 / kPerSup super-groups = k0 / kPerHyp hyper-groups;
+        // two per pair record
+        constexpr int kPerSup = kTriGroup * kTriSuper, kPerHyp = kPerSup * kTriHyper;
+        n_swept += anyhit_tri_groups_filter(
+            SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) +
+                                 ((p.tg.n_grp + p.tg.n_sup) >> 1) + k0 / (2 * kPerHyp)},
+            SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) +
+                                 (p.tg.n_grp >> 1) + k0 / (2 * kPerSup)},
+            SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) + (k0 >> 4)},
+            SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.sorted2_pf) + (k0 >> 1)},
+            SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tg.sorted2_f) + (k0 >> 1)},
+            SmemFetch<DevTri>{p.tg.sorted + k0}, n_here / kPerHyp, k0, so, sL, rs,
+            rt, far, aa,
+            n_open);
+        if (rr >= 0 && n_open) R.n_open[rr] += n_open;
+      } else if (in_tris) {
+        const V3<V> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
+        n_swept += n_here; // upper bound: exits inside a segment are not subtracted
+        if (p.use_filter && n_here >= 8) { // k0 is even: segment lengths are
+          bool far;
+          const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
+          const RayF rs = make_ray_filter(so, sL, p.shadow_center);
+          anyhit_tri_filter(
+              SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tri2_pf) + (k0 >> 1)},
+              SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tri2_f) + (k0 >> 1)},
+              SmemFetch<DevTri>{p.tri + k0}, n_here, k0, so, sL, rs, rt, far, aa);
+        } else {
+          anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri + k0}, n_here, k0, sov, sLv, aa);
+        }
+      } else if (grp) {
+        const RayF rf = make_ray_filter(so, sL, p.shadow_center);
+        const float a1 = (fabsf(so.x - p.shadow_center[0]) + fabsf(so.y - p.shadow_center[1])) +
+                         fabsf(so.z - p.shadow_center[2]);
+        const bool far = !(a1 <= p.shadow_rho_max); // also catches NaN
+        int n_open = 0;
+        if (!last_light) {
+          aa[0].orig = reinterpret_cast<const int32_t *>(p.sg.orig);
+          aa[0].orig_bias = aa[0].orig_add = p.n_tri;
+        }
+        // a light with one sample point this frame: the cells of its light lists (rt_lists.h)
+        // hold every sphere a ray's line can reach -- unless a ray starts outside the region
+        // the reach was computed for, or its cell overflowed: then the sweep below runs
+        bool served = false;
+        const bool outside = !(so.x >= p.scene_lo[0] && so.x <= p.scene_hi[0] && so.y >= p.scene_lo[1] &&
+                               so.y <= p.scene_hi[1] && so.z >= p.scene_lo[2] && so.z <= p.scene_hi[2]);
+        if (p.ll.enabled && li < p.ll.n_listed && n_rec <= kSegGroupPairs &&
+            __builtin_amdgcn_ballot_w64(aa[0].tb > 0.f && outside) == 0) {
+          const f3 Pl = ld3(p.light_points + 4 * p.ll.point[li]);
+          int n_tests = 0, sw = 0;
+          served = anyhit_sph_light_lists(
+              p.ll, light_list_cell(p.ll, li, Pl, so),
+              SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2)}, p.n_tri, so, sL, aa[0],
+              n_tests, sw);
+          n_swept += sw;
+          if (rr >= 0) R.n_open[rr] = (R.n_open[rr] + (n_tests >> 3)) | (served ? kListServed : 0);
+        }
+        if (!served)
+        // k0 pair records in = k0 / 4 groups = k0 / 32 super-groups = k0 / 256 hyper-groups; two per record
+        n_swept += anyhit_sph_groups_filter(
+            SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) +
+                             ((p.sg.n_grp + p.sg.n_sup) >> 1) + (k0 >> 9)},
+            SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (p.sg.n_grp >> 1) + (k0 >> 6)},
+            SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (k0 >> 3)},
+            SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.sorted2_f) + k0},
+            SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2) + k0}, n_here >> 8,
+            p.n_tri + 2 * k0, so, sL, rf, far, aa[0], n_open);
+        if (rr >= 0 && n_open) R.n_open[rr] += n_open;
+      } else if (p.use_filter) {
+        const RayF rf = make_ray_filter(so, sL, p.shadow_center);
+        n_swept += 2 * anyhit_sph_pairs_filter(
+                           SmemFetch<PairF>{reinterpret_cast<const PairF *>(sweep_f) + k0},
+                           SmemFetch<PairG>{reinterpret_cast<const PairG *>(sweep_e) + k0},
+                           n_here, p.n_tri + 2 * k0, so, sL, rf, aa[0]);
+      } else {
+        n_swept += 2 * anyhit_sph_pairs(
+                           SmemFetch<PairG>{reinterpret_cast<const PairG *>(sweep_e) + k0},
+                           n_here, p.n_tri + 2 * k0, so, sL, aa[0]);
+      }
+      if (aa[0].kocc >= 0) { // rr >= 0 here: a dead lane has tb = 0 and accepts nothing
+        R.tb[rr] = 0.f;
+        R.tocc[rr] = aa[0].tocc;
+        R.kocc[rr] = aa[0].kocc;
+      }
+    }
+    k0 += n_here;
+    if (sg >= 1 && seg < (1 << 29)) seg *= 2;
+  }
+  __syncthreads();
+  a[0].kocc = R.kocc[tid];
+  a[0].tocc = R.tocc[tid];
+  if (last_light) { // earlier lights report the reference's own count: their kocc is the
+    if (grp || tgrp) grp_open = R.n_open[tid]; // first occluder in index order
+    tri_groups = tgrp;
+    sph_groups = grp;
+  }
+  rL = mk(R.lx[tid], R.ly[tid], R.lz[tid]); // not kept live across the segments
+  N = mk(R.keep[0][tid], R.keep[1][tid], R.keep[2][tid]);
+  r = R.keep[3][tid]; g = R.keep[4][tid]; b = R.keep[5][tid];
+  t = R.keep[6][tid];
+  mi = __float_as_int(R.keep[7][tid]);
+}
+
 template <int STAGE, bool TGRP = false>
 __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) k_shade(const RenderParams p) {
   typedef float V;
@@ -891,171 +1080,8 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
         a[0].tocc = s.thit;
         cnt_lane = (uint32_t)n_tests;
       } else if constexpr (STAGE == STAGE_SMEM) {
-        // ---- segments of the primitive list, undecided rays re-packed in between
-        // (the LAST light sweeps the spheres by decreasing solid angle when the host built that
-        // order: its occluder is never read again -- rt_device.h sph2_ord)
-        const bool ord = (li == p.n_lights - 1) && p.sph2_ord != nullptr;
-        const DevSphPair *sweep_e = ord ? p.sph2_ord : p.sph2;
-        const DevSphPairF *sweep_f = ord ? p.sph2_f_ord : p.sph2_f;
-        RepackLds &R = lds_rays;
-        R.ox[tid] = ro.x; R.oy[tid] = ro.y; R.oz[tid] = ro.z;
-        R.lx[tid] = rL.x; R.ly[tid] = rL.y; R.lz[tid] = rL.z;
-        R.tb[tid] = a[0].tb;
-        R.kocc[tid] = -1;
-        R.tocc[tid] = 0.f;
-        R.n_open[tid] = 0;
-        R.keep[0][tid] = N.x; R.keep[1][tid] = N.y; R.keep[2][tid] = N.z;
-        R.keep[3][tid] = r; R.keep[4][tid] = g; R.keep[5][tid] = b;
-        R.keep[6][tid] = t; R.keep[7][tid] = __int_as_float(mi);
-        // Occluded rays mostly meet their occluder early in the list, so re-packing pays at
-        // the beginning and not later: segment lengths double (256, 256, 512, 1024, ...
-        // triangles; 512, 512, 1024, ... pair records), which keeps the barriers few.
-        // the last light sweeps the sphere GROUPS when the host built them (rt_device.h SphGroups):
-        // k0 then counts pair records of the sorted table, 4 per group, segments whole steps
-        // Lights before the last sweep the groups too, in "first occluder" mode (rt_brute.h Any:
-        // every group visited, the accepted primitive with the lowest original index kept) --
-        // as long as the whole table is one segment, which it is below 2^20 records.
-        const bool last_light = li == p.n_lights - 1;
-        const bool grp = p.use_filter && p.sg.n_grp > 0 &&
-                         (last_light || p.sg.n_grp * (kSphGroup / 2) <= kSegGroupPairs);
-        const int n_rec = grp ? p.sg.n_grp * (kSphGroup / 2) : (p.n_sph + 1) >> 1;
-        // ... and the triangle GROUPS (rt_device.h TriGroups): k0 counts sorted slots, 8 per group
-        const bool tgrp = TGRP && p.use_filter && p.tg.n_grp > 0 &&
-                          (last_light || p.tg.n_grp * kTriGroup <= kSegGroupPairs);
-        const int n_tri_sweep = tgrp ? p.tg.n_grp * kTriGroup : p.n_tri;
-        int k0 = 0, seg = tgrp ? kSegGroupPairs : kSegTris; // triangles first (index order)
-        bool in_tris = p.n_tri > 0;
-        const int seg_sph = grp ? kSegGroupPairs : kSegSphPairs;
-        if (!in_tris) seg = seg_sph;
-        for (int sg = 0;; ++sg) {
-          if (in_tris && k0 >= n_tri_sweep) {
-            in_tris = false;
-            k0 = 0;
-            seg = seg_sph;
-            sg = 0;
-          }
-          if (!in_tris && k0 >= n_rec) break;
-          const int n_here = min(seg, (in_tris ? n_tri_sweep : n_rec) - k0);
-          const int n_live = repack_rays(R, tid);
-          if (n_live == 0) break; // workgroup-uniform
-          if (wave * 64 < n_live) { // otherwise this wave sits the segment out
-            const int slot = wave * 64 + lane;
-            const int rr = (slot < n_live) ? (int)R.list[slot] : -1;
-            const int rs = (rr >= 0) ? rr : tid;
-            Any aa[1];
-            aa[0].tb = (rr >= 0) ? R.tb[rs] : 0.f;
-            aa[0].tocc = 0.f;
-            aa[0].kocc = -1;
-            aa[0].orig = nullptr;
-            aa[0].orig_bias = aa[0].orig_add = 0;
-            const f3 so = mk(R.ox[rs], R.oy[rs], R.oz[rs]);
-            const f3 sL = mk(R.lx[rs], R.ly[rs], R.lz[rs]);
-            if (TGRP && in_tris && tgrp) {
-              bool far;
-              const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
-              const RayF rs = make_ray_filter(so, sL, p.shadow_center);
-              int n_open = 0;
-              if (!last_light) aa[0].orig = reinterpret_cast<const int32_t *>(p.tg.orig); // bias, add 0
-              // k0 sorted slots in = k0 / 8 groups = k0 / kPerSup super-groups = k0 / kPerHyp hyper-groups;
-              // two per pair record
-              constexpr int kPerSup = kTriGroup * kTriSuper, kPerHyp = kPerSup * kTriHyper;
-              n_swept += anyhit_tri_groups_filter(
-                  SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) +
-                                       ((p.tg.n_grp + p.tg.n_sup) >> 1) + k0 / (2 * kPerHyp)},
-                  SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) +
-                                       (p.tg.n_grp >> 1) + k0 / (2 * kPerSup)},
-                  SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.grp2_pf) + (k0 >> 4)},
-                  SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tg.sorted2_pf) + (k0 >> 1)},
-                  SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tg.sorted2_f) + (k0 >> 1)},
-                  SmemFetch<DevTri>{p.tg.sorted + k0}, n_here / kPerHyp, k0, so, sL, rs,
-                  rt, far, aa,
-                  n_open);
-              if (rr >= 0 && n_open) R.n_open[rr] += n_open;
-            } else if (in_tris) {
-              const V3<V> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
-              n_swept += n_here; // upper bound: exits inside a segment are not subtracted
-              if (p.use_filter && n_here >= 8) { // k0 is even: segment lengths are
-                bool far;
-                const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
-                const RayF rs = make_ray_filter(so, sL, p.shadow_center);
-                anyhit_tri_filter(
-                    SmemFetch<TriPairPF>{reinterpret_cast<const TriPairPF *>(p.tri2_pf) + (k0 >> 1)},
-                    SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tri2_f) + (k0 >> 1)},
-                    SmemFetch<DevTri>{p.tri + k0}, n_here, k0, so, sL, rs, rt, far, aa);
-              } else {
-                anyhit_tri<V, NV>(SmemFetch<DevTri>{p.tri + k0}, n_here, k0, sov, sLv, aa);
-              }
-            } else if (grp) {
-              const RayF rf = make_ray_filter(so, sL, p.shadow_center);
-              const float a1 = (fabsf(so.x - p.shadow_center[0]) + fabsf(so.y - p.shadow_center[1])) +
-                               fabsf(so.z - p.shadow_center[2]);
-              const bool far = !(a1 <= p.shadow_rho_max); // also catches NaN
-              int n_open = 0;
-              if (!last_light) {
-                aa[0].orig = reinterpret_cast<const int32_t *>(p.sg.orig);
-                aa[0].orig_bias = aa[0].orig_add = p.n_tri;
-              }
-              // a light with one sample point this frame: the cells of its light lists (rt_lists.h)
-              // hold every sphere a ray's line can reach -- unless a ray starts outside the region
-              // the reach was computed for, or its cell overflowed: then the sweep below runs
-              bool served = false;
-              const bool outside = !(so.x >= p.scene_lo[0] && so.x <= p.scene_hi[0] && so.y >= p.scene_lo[1] &&
-                                     so.y <= p.scene_hi[1] && so.z >= p.scene_lo[2] && so.z <= p.scene_hi[2]);
-              if (p.ll.enabled && li < p.ll.n_listed && n_rec <= kSegGroupPairs &&
-                  __builtin_amdgcn_ballot_w64(aa[0].tb > 0.f && outside) == 0) {
-                const f3 Pl = ld3(p.light_points + 4 * p.ll.point[li]);
-                int n_tests = 0, sw = 0;
-                served = anyhit_sph_light_lists(
-                    p.ll, light_list_cell(p.ll, li, Pl, so),
-                    SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2)}, p.n_tri, so, sL, aa[0],
-                    n_tests, sw);
-                n_swept += sw;
-                if (rr >= 0) R.n_open[rr] = (R.n_open[rr] + (n_tests >> 3)) | (served ? kListServed : 0);
-              }
-              if (!served)
-              // k0 pair records in = k0 / 4 groups = k0 / 32 super-groups = k0 / 256 hyper-groups; two per record
-              n_swept += anyhit_sph_groups_filter(
-                  SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) +
-                                   ((p.sg.n_grp + p.sg.n_sup) >> 1) + (k0 >> 9)},
-                  SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (p.sg.n_grp >> 1) + (k0 >> 6)},
-                  SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.grp2_f) + (k0 >> 3)},
-                  SmemFetch<PairF>{reinterpret_cast<const PairF *>(p.sg.sorted2_f) + k0},
-                  SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2) + k0}, n_here >> 8,
-                  p.n_tri + 2 * k0, so, sL, rf, far, aa[0], n_open);
-              if (rr >= 0 && n_open) R.n_open[rr] += n_open;
-            } else if (p.use_filter) {
-              const RayF rf = make_ray_filter(so, sL, p.shadow_center);
-              n_swept += 2 * anyhit_sph_pairs_filter(
-                                 SmemFetch<PairF>{reinterpret_cast<const PairF *>(sweep_f) + k0},
-                                 SmemFetch<PairG>{reinterpret_cast<const PairG *>(sweep_e) + k0},
-                                 n_here, p.n_tri + 2 * k0, so, sL, rf, aa[0]);
-            } else {
-              n_swept += 2 * anyhit_sph_pairs(
-                                 SmemFetch<PairG>{reinterpret_cast<const PairG *>(sweep_e) + k0},
-                                 n_here, p.n_tri + 2 * k0, so, sL, aa[0]);
-            }
-            if (aa[0].kocc >= 0) { // rr >= 0 here: a dead lane has tb = 0 and accepts nothing
-              R.tb[rr] = 0.f;
-              R.tocc[rr] = aa[0].tocc;
-              R.kocc[rr] = aa[0].kocc;
-            }
-          }
-          k0 += n_here;
-          if (sg >= 1 && seg < (1 << 29)) seg *= 2;
-        }
-        __syncthreads();
-        a[0].kocc = R.kocc[tid];
-        a[0].tocc = R.tocc[tid];
-        if (last_light) { // earlier lights report the reference's own count: their kocc is the
-          if (grp || tgrp) grp_open = R.n_open[tid]; // first occluder in index order
-          tri_groups = tgrp;
-          sph_groups = grp;
-        }
-        rL = mk(R.lx[tid], R.ly[tid], R.lz[tid]); // not kept live across the segments
-        N = mk(R.keep[0][tid], R.keep[1][tid], R.keep[2][tid]);
-        r = R.keep[3][tid]; g = R.keep[4][tid]; b = R.keep[5][tid];
-        t = R.keep[6][tid];
-        mi = __float_as_int(R.keep[7][tid]);
+        shadow_sweep_smem<TGRP>(p, lds_rays, tid, wave, lane, li, ro, rL, a, N, r, g, b, t, mi, grp_open,
+                                tri_groups, sph_groups, n_swept);
       } else {
         const V3<V> ov[1] = {{ro.x, ro.y, ro.z}}, Lv[1] = {{rL.x, rL.y, rL.z}};
         constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTri);
@@ -1122,6 +1148,266 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
     emit_counters(p, tid, lane, inside, has_hit, n_shadow, n_any, (unsigned long long)n_swept * 64ull,
                   true);
     write_tile(p, T, tid, r, g, b, inside, lds_px);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_frame: the whole frame of the default path in ONE kernel -- k_primary's closest hit (2 pixels per
+// lane: a workgroup owns a 64 x 8 tile) followed, for each of the lane's two pixels in turn, by
+// k_shade<SMEM>'s shading with the workgroup's 256 rays re-packed between segments.  What it saves
+// over the two kernels: the hit planes (4-12 B per pixel written and read back: 2.2x the
+// algorithmic HBM traffic on c4 became 1.1x), the primary direction computed three times per hit
+// pixel (two divides, a square root and three more divides each), one launch.  The two halves
+// still want different register budgets; they meet through LDS: after the sweep every lane parks
+// dir, t, v, idx of both pixels (12 KB per workgroup) and the shading loop -- not unrolled, so one
+// copy of its code -- picks one pixel up at a time; the finished colours go back into the same
+// slots and the tile is stored from there, each store instruction writing consecutive dwords of
+// one image row.  Same functions as the two-kernel path (primary_closest, shadow_sweep_smem,
+// phong_add): same arithmetic, same image.  ESC_RENDER_TWO_KERNELS keeps k_primary + k_shade.
+// ---------------------------------------------------------------------------------------
+DEVINL Tile<2> tile_again2(const RenderParams &p) { // (see tile_again)
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int tiles_x = (p.W + 63) / 64;
+  Tile<2> T(p, blockIdx.x % tiles_x, blockIdx.x / tiles_x, t);
+  T.wave = __builtin_amdgcn_readfirstlane(T.wave);
+  return T;
+}
+
+// counters of a workgroup whose lanes carry several pixels: per-lane counts in, one atomic per
+// counter and workgroup out (emit_counters' scheme).  All 256 threads (barriers inside).
+DEVINL void emit_counters_n(const RenderParams &p, int tid, int lane, uint32_t n_inside, uint32_t n_hit,
+                            uint32_t n_shadow, unsigned long long n_any_wave,
+                            unsigned long long lane_tests_wave) {
+  if (!p.counters) return;
+  __shared__ unsigned long long wg_cnt[5];
+  if (tid < 5) wg_cnt[tid] = 0ull;
+  __syncthreads();
+  uint32_t ni = n_inside, nh = n_hit, ns = n_shadow;
+  for (int o = 32; o > 0; o >>= 1) {
+    ni += __shfl_down(ni, o);
+    nh += __shfl_down(nh, o);
+    ns += __shfl_down(ns, o);
+  }
+  if (lane == 0) {
+    atomicAdd(&wg_cnt[0], (unsigned long long)ni);
+    atomicAdd(&wg_cnt[1], (unsigned long long)nh);
+    atomicAdd(&wg_cnt[2], (unsigned long long)ns);
+    atomicAdd(&wg_cnt[3], n_any_wave);
+    atomicAdd(&wg_cnt[4], lane_tests_wave);
+  }
+  __syncthreads();
+  if (tid < 5 && wg_cnt[tid])
+    atomicAdd(&p.counters[(blockIdx.x % kCounterSets) * 8 + tid], wg_cnt[tid]);
+}
+
+// the 64 x 8 tile of k_frame out of its LDS slots: park[q][c][thread] holds channel c of pixel q of
+// that thread.  Pixel (row, x) of the tile belongs to wave (row / 4) * 2 + x / 32, lane (row % 4) *
+// 16 + x % 16, pixel q = (x / 16) % 2 (the Tile<2> layout).  Called by all 256 threads after a barrier.
+DEVINL int tile64_owner(int row, int x, int &q) {
+  q = (x >> 4) & 1;
+  return (((row >> 2) * 2 + (x >> 5)) << 6) + ((row & 3) << 4) + (x & 15);
+}
+DEVINL uint8_t quantise_channel(float c) { // main.cpp:676-682 clamp > 1, int(c * 255)
+  const float cc = (c > 1.f) ? 1.f : c;
+  return (uint8_t)(int)(cc * 255.f);
+}
+DEVINL void write_tile64(const RenderParams &p, const Tile<2> &T, int tid, const float (*park)[6][256]) {
+  constexpr int TW = 64;
+  const int rows = p.n_local_rows;
+  const int w0 = T.w0, lr0 = T.lr0;
+  const bool full_tile = (w0 + TW <= p.W) && (lr0 + kTileH <= rows) && (T.h_tile + kTileH <= p.H);
+  const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly;
+  if (p.out_f32) {
+    if (full_tile) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int idx = tid + 256 * i; // 0 .. 1535
+        const int row = idx / (TW * 3), col = idx % (TW * 3);
+        int q;
+        const int own = tile64_owner(row, col / 3, q);
+        p.out_f32[((size_t)(lr0 + row) * p.W + w0) * 3 + col] = park[q][col % 3][own];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int w = T.w0 + T.lx0 + 16 * q;
+        if (lr < rows && h < p.H && w < p.W) {
+          const size_t o = ((size_t)lr * p.W + w) * 3;
+          p.out_f32[o + 0] = park[q][0][tid];
+          p.out_f32[o + 1] = park[q][1][tid];
+          p.out_f32[o + 2] = park[q][2][tid];
+        }
+      }
+    }
+  }
+  if (p.out_u8) {
+    if (full_tile && (p.W & 3) == 0) {
+      constexpr int ROW_DW = TW * 3 / 4; // 48 dwords per tile row
+      for (int d = tid; d < ROW_DW * kTileH; d += 256) {
+        const int row = d / ROW_DW, cb = (d % ROW_DW) * 4;
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int q;
+          const int own = tile64_owner(row, (cb + k) / 3, q);
+          word |= (uint32_t)quantise_channel(park[q][(cb + k) % 3][own]) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(p.out_u8 + ((size_t)(lr0 + row) * p.W + w0) * 3 + cb) = word;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int w = T.w0 + T.lx0 + 16 * q;
+        if (lr < rows && h < p.H && w < p.W) {
+          const size_t o = ((size_t)lr * p.W + w) * 3;
+          p.out_u8[o + 0] = quantise_channel(park[q][0][tid]);
+          p.out_u8[o + 1] = quantise_channel(park[q][1][tid]);
+          p.out_u8[o + 2] = quantise_channel(park[q][2][tid]);
+        }
+      }
+    }
+  }
+}
+
+template <bool GRP, bool TGRP>
+__global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams p) {
+  __shared__ RepackLds lds_rays;
+  __shared__ float park[2][6][256]; // per pixel q of thread t: dir xyz, t, v, idx; later r, g, b
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[16];
+  const int tid = threadIdx.x;
+  { // ---- camera.h:31-34 + main.cpp:722: both pixels of every lane (k_primary's body)
+    const Tile<2> T(p);
+    const int h = T.h_tile + T.ly;
+    f3 dir[2];
+    Hit hit[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      dir[q] = primary_dir(p, T.w0 + T.lx0 + 16 * q, h);
+      hit[q].t = FLT_MAX; // main.cpp:715
+      hit[q].v = 0.f;
+      hit[q].idx = -1;
+    }
+    V3<v2f> dv[1];
+    pack3<v2f, 1>(dir, dv);
+    primary_closest<STAGE_SMEM, v2f, 1, GRP, 2>(p, T, dv, hit, lds_raw);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      park[q][0][tid] = dir[q].x;
+      park[q][1][tid] = dir[q].y;
+      park[q][2][tid] = dir[q].z;
+      park[q][3][tid] = hit[q].t;
+      park[q][4][tid] = hit[q].v;
+      park[q][5][tid] = __int_as_float(hit[q].idx);
+    }
+  }
+  // (every slot above is read back by the thread that wrote it: no barrier needed until the store)
+  const f3 origin = mk(p.origin[0], p.origin[1], p.origin[2]);
+  const float nl = (float)p.n_lights;
+  uint32_t n_inside = 0, n_hit = 0, n_shadow = 0;
+  unsigned long long n_any = 0; // wave-uniform
+  int n_swept = 0;
+#pragma unroll 1
+  for (int q = 0; q < 2; ++q) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    bool has_hit;
+    float t;
+    f3 N = mk(0.f, 0.f, 0.f);
+    int mi = 0;
+    { // ---- main.cpp:723-738 normal of the hit
+      const Tile<2> Ta = tile_again2(p);
+      const bool inside = (Ta.lr0 + Ta.ly < p.n_local_rows) && (Ta.h_tile + Ta.ly < p.H) &&
+                          (Ta.w0 + Ta.lx0 + 16 * q < p.W);
+      const int idx = __float_as_int(park[q][5][tid]);
+      has_hit = inside && idx >= 0;
+      t = park[q][3][tid];
+      n_inside += inside ? 1u : 0u;
+      n_hit += has_hit ? 1u : 0u;
+      if (has_hit) {
+        if (idx < p.n_tri) {
+          const DevTri Tr = p.tri[idx];
+          N = normalize(cross(ld3(Tr.e1), ld3(Tr.e2))); // :728-731
+          mi = Tr.geom;
+          if (p.mat[mi].has_normals) { // :733-738 with u == 0 (quirk S1)
+            const DevTriN Q = p.tri_n[idx];
+            const float u = 0.f, v = park[q][4][tid];
+            N = normalize((ld3(Q.n1) * u + ld3(Q.n2) * v) + ld3(Q.n0) * ((1.f - u) - v));
+          }
+        } else {
+          const int k = idx - p.n_tri;
+          const DevSph S = p.sph[k];
+          const f3 dir = mk(park[q][0][tid], park[q][1][tid], park[q][2][tid]);
+          N = normalize((origin + dir * t) - mk(S.cx, S.cy, S.cz)); // extension
+          mi = p.sph_mat[k];
+        }
+      }
+    }
+    // ---- main.cpp:740-789 per-light shading (k_shade<SMEM>'s loop)
+    float r = 0.f, g = 0.f, b = 0.f; // vec3 default ctor, main.cpp:557-558
+    for (int li = 0; li < p.n_lights; ++li) {
+      const DevLight Lt = p.lights[li];
+      Any a[1];
+      int grp_open = 0;
+      bool tri_groups = false, sph_groups = false;
+      uint32_t cnt_lane = 0;
+      f3 ro = N, rL = N;
+      a[0].tb = 0.f;
+      a[0].tocc = 0.f;
+      a[0].kocc = -1;
+      a[0].orig = nullptr;
+      a[0].orig_bias = a[0].orig_add = 0;
+      if (has_hit) {
+        uint32_t face = (p.face_mode == 0) ? (uint32_t)p.fixed_face : 0u;
+        if (p.face_mode != 0 && Lt.n_faces != 1) { // x % 1 == 0: a one-face light needs no draw
+          const Tile<2> Ta = tile_again2(p);
+          face = face_hash(p.seed, (uint32_t)((Ta.h_tile + Ta.ly) * p.W + Ta.w0 + Ta.lx0 + 16 * q),
+                           (uint32_t)li, (uint32_t)Lt.n_faces);
+        }
+        const f3 P = ld3(p.light_points + 4 * (Lt.first_point + (int)face)); // quirk S2
+        const f3 dir = mk(park[q][0][tid], park[q][1][tid], park[q][2][tid]);
+        ro = origin + dir * (t - FLT_EPSILON); // :757-758
+        rL = P - ro;                           // :759
+        const float len = length(rL);          // :761
+        t = len - FLT_EPSILON;                 // :764
+        rL = normalize(rL);                    // :766
+        a[0].tb = t;
+      }
+      if (!(a[0].tb > 0.f)) a[0].tb = 0.f; // dead rays carry tb = 0
+      if (p.shadows)
+        shadow_sweep_smem<TGRP>(p, lds_rays, tid, wave, lane, li, ro, rL, a, N, r, g, b, t, mi, grp_open,
+                                tri_groups, sph_groups, n_swept);
+      if (has_hit) {
+        if (p.shadows) {
+          n_shadow += 1u;
+          const int k = a[0].kocc; // (the counter rules of k_shade)
+          const bool by_tri = k >= 0 && k < p.n_tri;
+          unsigned cnt = tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper * kTriHyper) + 1
+                                                        : p.tg.n_hyp)
+                                    : (unsigned)(by_tri ? k + 1 : p.n_tri);
+          if (!by_tri && !(grp_open & kListServed))
+            cnt += sph_groups ? (unsigned)(k >= 0 ? ((k - p.n_tri) >> 9) + 1 : p.sg.n_hyp)
+                              : (unsigned)(k >= 0 ? k - p.n_tri + 1 : p.n_sph);
+          cnt_lane = cnt + 8u * (unsigned)(grp_open & ~kListServed);
+        }
+        if (p.shadows && a[0].kocc >= 0) {
+          t = a[0].tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
+        } else {         // :772-773 `continue` otherwise
+          phong_add(p.mat[mi], N, rL, nl, r, g, b); // :768-788
+        }
+      }
+      if (p.counters && p.shadows) n_any += wave_sum(cnt_lane); // wave-uniform
+    }
+    park[q][0][tid] = r; // the pixel's slots now hold its colour
+    park[q][1][tid] = g;
+    park[q][2][tid] = b;
+  }
+  {
+    const Tile<2> Te = tile_again2(p);
+    const int tid_e = Te.wave * 64 + Te.lane;
+    emit_counters_n(p, tid_e, Te.lane, n_inside, n_hit, n_shadow, Te.lane == 0 ? n_any : 0ull,
+                    Te.lane == 0 ? (unsigned long long)n_swept * 64ull : 0ull);
+    __syncthreads(); // every pixel's colour is in its slot
+    write_tile64(p, Te, tid_e, park);
   }
 }
 
@@ -1547,7 +1833,7 @@ extern "C" int esc_launch_primary_only(const esc::RenderParams *p, int px, hipSt
 // stage: 1 SMEM (always 2 px), 2 LDS, 3 BVH (px ignored).  px: pixels per work-item of the LDS primary pass (1, 2 or 4); the shade
 // pass always carries one pixel per work-item.
 extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, hipStream_t stream,
-                                 hipEvent_t between) {
+                                 hipEvent_t between, int two_kernels) {
   if (p->n_local_rows <= 0 || p->W <= 0) return 0;
   using esc::v2f;
   const int tiles_y = (p->n_local_rows + esc::kTileH - 1) / esc::kTileH;
@@ -1560,6 +1846,16 @@ extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, 
     else launch_primary<esc::STAGE_LDS, v2f, 2>(p, stream);
     if (between) (void)hipEventRecord(between, stream);
     hipLaunchKernelGGL((esc::k_shade<esc::STAGE_LDS>), dim3(shade_grid), dim3(256), 0, stream, *p);
+  } else if (!two_kernels && !between) { // the whole frame in one kernel (k_frame)
+    const int grid = ((p->W + 63) / 64) * tiles_y;
+    const bool grp = p->use_filter && (p->sg.n_grp > 0 || p->tg.n_grp > 0);
+    const bool tgrp = p->use_filter && p->tg.n_grp > 0;
+    if (tgrp)
+      hipLaunchKernelGGL((esc::k_frame<true, true>), dim3(grid), dim3(256), 0, stream, *p);
+    else if (grp)
+      hipLaunchKernelGGL((esc::k_frame<true, false>), dim3(grid), dim3(256), 0, stream, *p);
+    else
+      hipLaunchKernelGGL((esc::k_frame<false, false>), dim3(grid), dim3(256), 0, stream, *p);
   } else {
     launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream); // always 2 px: see esc_launch_primary_only
     if (between) (void)hipEventRecord(between, stream);

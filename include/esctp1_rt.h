@@ -192,7 +192,13 @@ enum {
 enum {
   ESC_STAGE_AUTO = 0, /* fastest measured variant per pass */
   ESC_STAGE_SMEM = 1, /* primitives broadcast through the scalar cache into SGPRs */
-  ESC_STAGE_LDS = 2,  /* primitives staged in LDS chunks by the workgroup */
+  ESC_STAGE_LDS = 2,  /* primitives staged in LDS chunks by the workgroup: north_star's sketch, kept as
+                         the REFERENCE-ARITHMETIC A/B PATH -- every (ray, primitive) pair runs the
+                         reference's operations, no filters, no groups, no lists.  Not a performance
+                         path: 20 % behind the scalar-cache staging when both ran that arithmetic
+                         (round 1), one to two orders of magnitude behind the default today
+                         (profiles/r03_final/stage_lds.txt).  What it is for: an independent
+                         cross-check in the tests (same image, the reference's any-hit count). */
   ESC_STAGE_BVH = 3   /* opt-in acceleration structure (what the reference's --bvh flag meant to
                          be, main.cpp:98-171,331-415): screen-space bins for primary rays,
                          light-space bins for shadow rays and a bounding-volume tree behind both
@@ -261,7 +267,12 @@ enum {
    * (csrc/rt_lists.h "Light lists"); a wavefront looks its rays' cells up and tests those lists with
    * the reference arithmetic.  This flag (or $ESC_LLISTS=0) keeps the three-level group sweep for
    * every shadow ray; rays the lists cannot serve take it anyway. */
-  ESC_RENDER_NO_LIGHT_LISTS = 64
+  ESC_RENDER_NO_LIGHT_LISTS = 64,
+  /* The default frame of the scalar-cache staging is ONE kernel (k_frame: closest hit and shading
+   * of a 64 x 8 tile; no hit planes through HBM).  This flag (or $ESC_FRAME=2) keeps the two kernels
+   * of rounds 1-2, k_primary + k_shade -- the A/B switch, and what ESC_RENDER_TIME_KERNELS and the
+   * queue form of the shading pass use anyway.  Same arithmetic, same image. */
+  ESC_RENDER_TWO_KERNELS = 128
 };
 
 typedef struct {
