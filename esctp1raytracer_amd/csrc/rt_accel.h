@@ -250,7 +250,7 @@ DEVINL void bvh_walk(const BvhRef &R, f3 o, f3 d, RaySt &s, bool alive, Leaf lea
 // the WAVE tested (wave-uniform).  PRIMARY: every ray starts at the camera, so the leaves are read
 // in their hoisted per-frame form (k_prepare_bvh).  A handful of triangles (a floor, a light)
 // is not worth a tree: up to kTinyTris are simply tested in index order from the flat tables.
-constexpr int kTinyTris = 4;
+// (kTinyTris: rt_device.h)
 template <int MODE, bool PRIMARY>
 DEVINL void bvh_trace(const RenderParams &p, f3 o, f3 d, RaySt &s, bool alive, int &n_visits,
                       int &n_tests, int &n_swept) {

@@ -1340,6 +1340,16 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     }
   if (n_local_rows == 0) return ESC_OK;
   HIP_TRY(hipSetDevice(ctx->device));
+  // ESC_STAGE_BVH culls with proven bounds only.  Its tree and bins are proven for spheres (box pads
+  // from the discriminant's error bound) and for up to kTinyTris triangles (tested directly); the
+  // boxes of a triangle MESH carry a heuristic pad, so a scene with more triangles is
+  // served by the structure that is proven for them -- the tile / light lists over the group levels
+  // of the default path -- unless the caller asks for the tree by name.
+  int32_t eff_stage = opts->stage;
+  if (eff_stage == ESC_STAGE_BVH && ctx->n_tri > esc::kTinyTris && !(opts->flags & ESC_RENDER_BVH_HEURISTIC_PADS)) {
+    const char *e = std::getenv("ESC_BVH_TREE"); // =1: as if the flag were set (tests, tools, viewer)
+    if (!(e && std::strcmp(e, "1") == 0)) eff_stage = ESC_STAGE_AUTO;
+  }
 
   esc::RenderParams p;
   std::memset(&p, 0, sizeof(p));
@@ -1444,8 +1454,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       return e && std::strcmp(e, "0") == 0;
     }();
     const bool want = !env_nolists && !(opts->flags & ESC_RENDER_NO_TILE_LISTS) && p.use_filter &&
-                      (p.sg.n_grp > 0 || p.tg.n_grp > 0) && opts->stage != ESC_STAGE_LDS &&
-                      opts->stage != ESC_STAGE_BVH && (h0 % 4) == 0;
+                      (p.sg.n_grp > 0 || p.tg.n_grp > 0) && eff_stage != ESC_STAGE_LDS &&
+                      eff_stage != ESC_STAGE_BVH && (h0 % 4) == 0;
     if (want) {
       const int tiles_x = (W + 31) / 32, tile_rows = (n_local_rows + 3) / 4;
       const size_t n_tiles = (size_t)tiles_x * tile_rows;
@@ -1515,8 +1525,8 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
            (opts->face_mode == ESC_FACE_FIXED || ctx->h_lights[(size_t)n_listed].n_faces == 1))
       n_listed++;
     const bool want = !env_nollists && !(opts->flags & ESC_RENDER_NO_LIGHT_LISTS) && p.use_filter &&
-                      p.shadows && p.sg.n_grp > 0 && n_listed > 0 && opts->stage != ESC_STAGE_LDS &&
-                      opts->stage != ESC_STAGE_BVH;
+                      p.shadows && p.sg.n_grp > 0 && n_listed > 0 && eff_stage != ESC_STAGE_LDS &&
+                      eff_stage != ESC_STAGE_BVH;
     if (want) {
       const int Rr = esc::kLightListRes;
       const size_t cells = (size_t)n_listed * 6 * Rr * Rr;
@@ -1558,10 +1568,10 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
       }
     }
   }
-  int stage = (opts->stage == ESC_STAGE_LDS) ? 2 : 1; // AUTO -> SMEM (measured)
+  int stage = (eff_stage == ESC_STAGE_LDS) ? 2 : 1; // AUTO -> SMEM (measured)
   // pixels per work-item of the PRIMARY pass; AUTO = 2 (measured)
   int px = opts->pixels_per_lane ? opts->pixels_per_lane : 2;
-  if (opts->stage == ESC_STAGE_BVH) {
+  if (eff_stage == ESC_STAGE_BVH) {
     if (!ctx->accel_valid || !ctx->accel_ob.contains(cam->origin)) {
       int rc = build_accel_device(ctx, cam->origin);
       if (rc) return rc;
@@ -1646,7 +1656,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   const int64_t eff_tri = tri_grouped ? 0 : p.n_tri;
   const bool queue_form =
       stage == 1 && p.shadows && p.n_lights > 0 && want != 1 &&
-      (want == 2 || opts->stage == ESC_STAGE_AUTO) &&
+      (want == 2 || eff_stage == ESC_STAGE_AUTO) &&
       (want == 2 || (eff_tri + eff_sph >= kQueueMinPrims &&
                      (int64_t)n_local_rows * W >= kQueueMinPixels));
   if (queue_form) {

@@ -385,6 +385,7 @@ struct alignas(64) BvhNode {
   uint32_t minkey[2];   // smallest primitive key below each child (key = index in triangles-then-
                         // spheres order, the order occlusion() meets primitives, main.cpp:314-329)
 };
+constexpr int kTinyTris = 4; // up to this many triangles are tested directly, no tree (and none of its pads)
 constexpr int kTriBlock = 2; // triangles per leaf block
 constexpr int kSphBlock = 4; // spheres per leaf block
 constexpr int kBvhMaxDepth = 60; // nodes on a root-to-leaf path; the walk's stack is one VGPR (64 lanes)

@@ -9,7 +9,9 @@
 //   --thread --test --debug --trace                          accepted (the CPU-side strategies
 //                                                            they selected are retired)
 //   --bvh         render through the acceleration structure (ESC_STAGE_BVH): what the flag was
-//                 meant to do in the reference (main.cpp:566-570,792-800), same image as without
+//                 meant to do in the reference (main.cpp:566-570,792-800), same image as without;
+//                 proven bounds only (triangle meshes go through the default path's lists / groups)
+//   --bvh-tree    the tree for triangle meshes as well (ESC_RENDER_BVH_HEURISTIC_PADS)
 //   --ispc        render through the `trace` drop-in symbol on flatten_scene_ispc-style arrays, in
 //                 (geometry, face) order: the scalar path's image bit for bit.  NOT the reference's
 //                 centroid-x sort (flatten_iscp.cpp:110) -- parity with the reference's own --ispc
@@ -63,7 +65,7 @@ void parse_floats(const char *flag, char *arg, float *out, int n, const char *er
 
 int main(int argc, char *argv[]) {
   std::string modelname, outputname, dumpname, synthetic;
-  bool threaded = false, flat = false, ispc = false, use_rccl = false, ispc_sorted = false;
+  bool threaded = false, flat = false, ispc = false, use_rccl = false, ispc_sorted = false, bvh_tree = false;
   int debug = 1; // INFO, debug.h:3
   float eye[3] = {0, 1, 3}, look[3] = {0, 1, 0}; // main.cpp:426
   int W = 1024, H = 768;                         // main.cpp:427
@@ -92,6 +94,7 @@ int main(int argc, char *argv[]) {
       continue;
     }
     if (a == "--gpus") { if (!next) die("--gpus needs N"); gpus = std::atoi(next); arg++; continue; }
+    if (a == "--bvh-tree") { flat = bvh_tree = true; continue; }
     if (a == "--rccl") { use_rccl = true; continue; }
     if (a == "--no-rccl") { use_rccl = false; continue; } // (the default; kept for old command lines)
     if (a == "--ispc-sorted") { ispc = ispc_sorted = true; continue; }
@@ -135,6 +138,7 @@ int main(int argc, char *argv[]) {
   opts.seed = seed;
   if (flat) opts.stage = ESC_STAGE_BVH; // tree build happens inside the timed region, like the
                                         // reference's buildBVH sits before its render clock
+  if (bvh_tree) opts.flags |= ESC_RENDER_BVH_HEURISTIC_PADS;
 
   // Device set-up is to this program what dynamic linking is to the reference: it happens before
   // the clock.  One device: context, scene tables in HBM and the kernels' code object (a 2x2

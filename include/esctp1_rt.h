@@ -203,8 +203,10 @@ enum {
                          be, main.cpp:98-171,331-415): screen-space bins for primary rays,
                          light-space bins for shadow rays and a bounding-volume tree behind both
                          cull primitives before the same exact tests run, so the image is the
-                         brute-force image.  One kernel per frame.
-                         Never chosen by AUTO: BASELINE's configs are brute force. */
+                         brute-force image.  One kernel per frame.  Proven bounds
+                         only: triangle meshes go through the default path's lists and groups
+                         unless ESC_RENDER_BVH_HEURISTIC_PADS asks for the tree.
+                         Never chosen by AUTO. */
 };
 
 typedef struct {
@@ -272,7 +274,16 @@ enum {
    * of a 64 x 8 tile; no hit planes through HBM).  This flag (or $ESC_FRAME=2) keeps the two kernels
    * of rounds 1-2, k_primary + k_shade -- the A/B switch, and what ESC_RENDER_TIME_KERNELS and the
    * queue form of the shading pass use anyway.  Same arithmetic, same image. */
-  ESC_RENDER_TWO_KERNELS = 128
+  ESC_RENDER_TWO_KERNELS = 128,
+  /* ESC_STAGE_BVH culls with PROVEN bounds only: spheres through its tree and bins (box pads from
+   * the error bound of the discriminant), triangle meshes (more than 4 triangles) through the tile /
+   * light lists and group levels of the default path, whose reach statements cover the reference's
+   * rounding-noise accepts for rays that graze a triangle's plane.  This flag sends triangle meshes
+   * through the tree as well: its triangle boxes carry a HEURISTIC pad (2^-12 of the scene's
+   * scale) -- faster on large meshes, every test and hunt so far bit-identical, but for rays within
+   * ~1e-3 rad of a triangle's plane whose rounding-noise hit lies further than the pad outside the
+   * triangle it may cull a hit the reference reports. */
+  ESC_RENDER_BVH_HEURISTIC_PADS = 256
 };
 
 typedef struct {

@@ -24,3 +24,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# ESC_STAGE_BVH culls triangle meshes with proven bounds (the default path's lists and groups) unless
+# ESC_RENDER_BVH_HEURISTIC_PADS / $ESC_BVH_TREE=1 asks for the tree and its heuristic triangle pads.
+# Tests that take the `bvh_tree` fixture run both ways.
+def pytest_generate_tests(metafunc):
+    if "bvh_tree" in metafunc.fixturenames:
+        metafunc.parametrize("bvh_tree", [False, True], ids=["proven", "tree"], indirect=True)
+
+
+@pytest.fixture
+def bvh_tree(request, monkeypatch):
+    on = bool(getattr(request, "param", False))
+    if on:
+        monkeypatch.setenv("ESC_BVH_TREE", "1")
+    return on

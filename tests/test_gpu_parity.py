@@ -574,7 +574,7 @@ def test_heightfield_c5_small(esc, renderer):
 # ---------------------------------------------------------------- reference-pinned twins
 @pytest.mark.parametrize("config,n,subdiv,smooth", [("c2", 100, 2, False), ("c3", 1000, 1, True),
                                                     ("c4", 10000, 0, False)])
-def test_icosphere_twins_of_the_sphere_configs(esc, renderer, config, n, subdiv, smooth):
+def test_icosphere_twins_of_the_sphere_configs(esc, renderer, config, n, subdiv, smooth, bvh_tree):
     """each sphere config has a twin made of the reference's only primitive --
     every sphere a tessellated icosahedron (32,003 / 80,003 / 200,003 triangles, one geometry per
     sphere; the c3 twin carries per-vertex normals, quirk S1) -- rendered at 160x90 with the
@@ -606,7 +606,7 @@ def test_icosphere_twins_of_the_sphere_configs(esc, renderer, config, n, subdiv,
             assert cnt["anyhit_tests"] == rc["anyhit_tests"]
 
 
-def test_cornellbox_water_largest_bundled_mesh(esc, renderer):
+def test_cornellbox_water_largest_bundled_mesh(esc, renderer, bvh_tree):
     """CornellBox-Water: 7,088 triangles in 9 geometries, the largest mesh the reference bundles
     (geometry = the reference loader's dump), two-face light with the hashed face choice.  Its
     water material has ks != 0, so device powf vs glibc powf may differ in the last ulp there:
@@ -956,7 +956,7 @@ def test_full_size_rows_vs_oracle(esc, renderer, config, W, H, rows):
                                       ("CornellBox-Original", (0, 1, 2)),
                                       ("CornellBox-Empty-CO", (0, 1, 3)),
                                       ("cornell_box", (0, 1, 3))])
-def test_bvh_triangle_scenes_vs_oracle(esc, renderer, name, eye):
+def test_bvh_triangle_scenes_vs_oracle(esc, renderer, name, eye, bvh_tree):
     d = ol.load_dump(name)
     gpu, u8, ref = render_both(esc, renderer, d, eye, (0, 1, 0), 160, 90,
                                stage=esc.ESC_STAGE_BVH)
@@ -988,7 +988,7 @@ def test_bvh_synthetic_scenes_vs_oracle(esc, renderer, config, n, shadows):
         assert cnt["anyhit_tests"] < rc["anyhit_tests"]
 
 
-def test_bvh_two_lights_first_occluder_in_order(esc, renderer):
+def test_bvh_two_lights_first_occluder_in_order(esc, renderer, bvh_tree):
     """Quirk S3 carries the FIRST occluder's t2 into the next light's shadow ray: with two
     lights and many overlapping occluders the walk must report the same one as the linear scan."""
     d = ol.load_dump("two")
@@ -1013,7 +1013,7 @@ def test_bvh_two_lights_first_occluder_in_order(esc, renderer):
 
 @pytest.mark.parametrize("elev", [1e-2, 1e-3, 1e-4, 1e-5])
 @pytest.mark.parametrize("dist", [30.0, 300.0])
-def test_bvh_grazing_rays_on_large_triangles(esc, renderer, elev, dist):
+def test_bvh_grazing_rays_on_large_triangles(esc, renderer, elev, dist, bvh_tree):
     """Rays that graze large triangles' planes from far away: the camera sits
     `dist` away from a 24 x 28 floor, `elev` radians above its plane, and looks along it, so every
     primary ray meets the floor plane at <= ~elev + fov/2 ... down to ~elev, and the image's
@@ -1045,7 +1045,7 @@ def test_bvh_grazing_rays_on_large_triangles(esc, renderer, elev, dist):
         assert_bit_equal(gpu, ref, f"grazing elev={elev} dist={dist} stage={stage}")
 
 
-def test_bvh_second_light_origin_outside_the_scene_box(esc, renderer):
+def test_bvh_second_light_origin_outside_the_scene_box(esc, renderer, bvh_tree):
     """Quirk S3 with two lights: light 2's shadow ray starts at camera + dir * (t_occ - eps), where
     t_occ is light 1's occluder distance ALONG ITS SHADOW RAY.  With light 1 far away and its
     occluder next to it, t_occ is several times the primary hit distance: the origin lies far
@@ -1077,7 +1077,7 @@ def test_bvh_second_light_origin_outside_the_scene_box(esc, renderer):
     assert ref.sum() > 0
 
 
-def test_bvh_third_light_origin_two_diagonals_out(esc, renderer):
+def test_bvh_third_light_origin_two_diagonals_out(esc, renderer, bvh_tree):
     """Quirk S3 with THREE lights: light 3's shadow ray starts at camera + dir * t where
     t was left by light 2's ray, which itself started far outside the scene and is therefore up to
     two scene diagonals long: OriginBounds' ball is (light points - 1) diagonals.  Light A far away
@@ -1114,14 +1114,14 @@ def test_bvh_third_light_origin_two_diagonals_out(esc, renderer):
 
 
 @pytest.mark.parametrize("W,H", [(33, 9), (97, 61), (2, 2), (31, 7)])
-def test_bvh_ragged_sizes(esc, renderer, W, H):
+def test_bvh_ragged_sizes(esc, renderer, W, H, bvh_tree):
     d = ol.load_dump("one")
     gpu, u8, ref = render_both(esc, renderer, d, (0, 1, 3), (0, 1, 0), W, H,
                                stage=esc.ESC_STAGE_BVH)
     assert_bit_equal(gpu, ref, f"bvh/{W}x{H}")
 
 
-def test_bvh_multi_band_single_process(esc):
+def test_bvh_multi_band_single_process(esc, bvh_tree):
     """esc_render_frame_multi: every band's context builds its own tree"""
     sc, d = synthetic_dict(esc, "c3", 400)
     eye, look = esc.synthetic_view()
@@ -1131,7 +1131,7 @@ def test_bvh_multi_band_single_process(esc):
     assert_bit_equal(img, ref, "bvh/render_multi")
 
 
-def test_bvh_camera_move_rebuilds(esc, renderer):
+def test_bvh_camera_move_rebuilds(esc, renderer, bvh_tree):
     """the box pads depend on where rays can start; leaving that region must rebuild"""
     sc, d = synthetic_dict(esc, "c3", 200)
     renderer.upload(sc)
@@ -1150,7 +1150,7 @@ def test_bvh_camera_move_rebuilds(esc, renderer):
                                              ("c4", 3840, 2160, True), ("c5", 7680, 4320, True),
                                              ("c4", 3840, 2160, False),
                                              ("c5", 7680, 4320, False)])
-def test_bvh_full_size_equals_brute_force(esc, renderer, config, W, H, bins, monkeypatch):
+def test_bvh_full_size_equals_brute_force(esc, renderer, config, W, H, bins, monkeypatch, bvh_tree):
     """BASELINE.json's sizes: every pixel of the BVH frame == the brute-force frame, with the
     screen / light bins and with the plain tree walk (ESC_BVH_BINS=0)."""
     import torch
@@ -1267,7 +1267,7 @@ def test_bvh_light_bins_awkward_lights(esc, renderer, case):
 
 
 @pytest.mark.parametrize("seed", list(range(16)))
-def test_bvh_random_scenes(esc, renderer, seed):
+def test_bvh_random_scenes(esc, renderer, seed, bvh_tree):
     """random triangle soup + spheres + 1..3 one-face lights, random camera inside or outside:
     brute force and the BVH stage (tree, screen bins, light bins) both equal the oracle"""
     rng = np.random.default_rng(1000 + seed)
@@ -1303,7 +1303,7 @@ def test_bvh_random_scenes(esc, renderer, seed):
     assert_bit_equal(bvh, ref, f"random/{seed}/bvh")
 
 
-def test_bvh_strips_equal_full_frame(esc, renderer):
+def test_bvh_strips_equal_full_frame(esc, renderer, bvh_tree):
     """the multi-GPU partition under ESC_STAGE_BVH: 8-row strips sit on the screen bins' 8-row
     grid, every rank's strips reproduce the rows of the full frame"""
     import torch
