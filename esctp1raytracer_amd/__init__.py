@@ -378,7 +378,8 @@ class Renderer:
 
 
     def tile_lists(self, which):
-        """the tile lists of the last frame (0: sphere groups, 1: triangle groups) -> dict with the
+        """the lists of the last frame (0 / 1: tile lists of spheres / triangles; 2 / 3: light lists of
+        sphere / triangle pair records) -> dict with the
         header numbers and the per-tile counts, or None when the frame used none"""
         hdr = (C.c_int32 * 8)()
         n = check(self._lib.esc_tile_list_counts(self._h, which, hdr, None, 0))

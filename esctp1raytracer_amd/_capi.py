@@ -159,6 +159,7 @@ SIGNATURES = {
     "esc_tri_group_record": (C.c_int, [_F, C.c_int32, _F]),
     "esc_sphere_group_record": (C.c_int, [_F, C.c_int32, _F]),
     "esc_tile_list_counts": (C.c_int, [C.c_void_p, C.c_int32, _I32, _I32, C.c_size_t]),
+    "esc_tile_list_ids": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, _I32, C.c_int32]),
     "esc_tile_rect": (C.c_int, [C.POINTER(esc_camera), C.c_int32, C.c_int32, _F, C.c_double, _I32]),
     "esc_tile_band": (C.c_int, [C.POINTER(esc_camera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F,
                                 C.c_double]),

@@ -107,7 +107,7 @@ struct esc_context {
   bool lists_valid = false;
   bool list_ids_stale = false; // a new scene: ids of the old one may be out of range
   // light lists of the shadow pass (rt_device.h LightLists), valid for (scene, ll_face_mode, ll_fixed_face)
-  esc::LightLists ll{};
+  esc::LightLists ll{}, lt{}; // sphere / triangle pair records
   int ll_alloc_lights = 0;
   int ll_face_mode = -1, ll_fixed_face = -1;
   bool ll_valid = false;
@@ -1525,42 +1525,49 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
            (opts->face_mode == ESC_FACE_FIXED || ctx->h_lights[(size_t)n_listed].n_faces == 1))
       n_listed++;
     const bool want = !env_nollists && !(opts->flags & ESC_RENDER_NO_LIGHT_LISTS) && p.use_filter &&
-                      p.shadows && p.sg.n_grp > 0 && n_listed > 0 && eff_stage != ESC_STAGE_LDS &&
-                      eff_stage != ESC_STAGE_BVH;
+                      p.shadows && (p.sg.n_grp > 0 || p.tg.n_grp > 0) && n_listed > 0 &&
+                      eff_stage != ESC_STAGE_LDS && eff_stage != ESC_STAGE_BVH;
     if (want) {
       const int Rr = esc::kLightListRes;
       const size_t cells = (size_t)n_listed * 6 * Rr * Rr;
       if (n_listed > ctx->ll_alloc_lights) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         int rc;
-        if ((rc = alloc_dev(ctx->ll.hdr, (size_t)n_listed * 6 * esc::kTileHdrInts))) return rc;
-        if ((rc = alloc_dev(ctx->ll.cnt, cells))) return rc;
-        if ((rc = alloc_dev(ctx->ll.ids, cells * esc::kLightListCap))) return rc;
+        for (esc::LightLists *L : {&ctx->ll, &ctx->lt}) {
+          if ((rc = alloc_dev(L->hdr, (size_t)n_listed * 6 * esc::kTileHdrInts))) return rc;
+          if ((rc = alloc_dev(L->cnt, cells))) return rc;
+          if ((rc = alloc_dev(L->ids, cells * esc::kLightListCap))) return rc;
+        }
+        if ((rc = alloc_dev(ctx->lt.esc, (size_t)n_listed * esc::kLightEscCap))) return rc;
         ctx->ll_alloc_lights = n_listed;
         ctx->ll_valid = false;
       }
-      esc::LightLists L = ctx->ll;
-      L.n_listed = n_listed;
-      L.R = Rr;
-      L.enabled = 1;
-      for (int li = 0; li < n_listed; li++)
-        L.point[li] = ctx->h_lights[(size_t)li].first_point +
-                      (opts->face_mode == ESC_FACE_FIXED ? opts->fixed_face : 0);
-      p.ll = L;
+      for (esc::LightLists *src : {&ctx->ll, &ctx->lt}) {
+        esc::LightLists L = *src;
+        L.n_listed = n_listed;
+        L.R = Rr;
+        L.enabled = (src == &ctx->ll) ? (p.sg.n_grp > 0) : (p.tg.n_grp > 0);
+        for (int li = 0; li < n_listed; li++)
+          L.point[li] = ctx->h_lights[(size_t)li].first_point +
+                        (opts->face_mode == ESC_FACE_FIXED ? opts->fixed_face : 0);
+        (src == &ctx->ll ? p.ll : p.lt) = L;
+      }
       if (!ctx->ll_valid || ctx->ll_face_mode != opts->face_mode ||
           (opts->face_mode == ESC_FACE_FIXED && ctx->ll_fixed_face != opts->fixed_face) ||
           ctx->ll.n_listed != n_listed) {
-        HIP_TRY(hipMemsetAsync(L.hdr, 0, (size_t)n_listed * 6 * esc::kTileHdrInts * 4, ctx->stream));
-        HIP_TRY(hipMemsetAsync(L.cnt, 0, cells * 4, ctx->stream));
-        // spare slots of a cell are read in whole batches of 4: zeros are valid pair records
-        HIP_TRY(hipMemsetAsync(L.ids, 0, cells * esc::kLightListCap * 4, ctx->stream));
+        for (const esc::LightLists *L : {&p.ll, &p.lt}) {
+          HIP_TRY(hipMemsetAsync(L->hdr, 0, (size_t)n_listed * 6 * esc::kTileHdrInts * 4, ctx->stream));
+          HIP_TRY(hipMemsetAsync(L->cnt, 0, cells * 4, ctx->stream));
+          // spare slots of a cell are read in whole batches of 4: zeros are valid pair records
+          HIP_TRY(hipMemsetAsync(L->ids, 0, cells * esc::kLightListCap * 4, ctx->stream));
+        }
         int e = esc_launch_light_lists(&p, ctx->stream);
         if (e) {
-          set_error(std::string("k_bin_light_pairs launch: ") + hipGetErrorString((hipError_t)e));
+          set_error(std::string("k_bin_light_* launch: ") + hipGetErrorString((hipError_t)e));
           return ESC_ERR_HIP;
         }
-        ctx->ll.n_listed = n_listed;
-        ctx->ll.R = Rr;
+        ctx->ll.n_listed = ctx->lt.n_listed = n_listed;
+        ctx->ll.R = ctx->lt.R = Rr;
         ctx->ll_face_mode = opts->face_mode;
         ctx->ll_fixed_face = opts->fixed_face;
         ctx->ll_valid = true;
@@ -1885,26 +1892,29 @@ void camera_params(const esc_camera *cam, int32_t W, int32_t H, esc::RenderParam
 
 int esc_tile_list_counts(esc_context *ctx, int32_t which, int32_t hdr[8], int32_t *counts,
                          size_t capacity) {
-  if (!ctx || !hdr || which < 0 || which > 2) {
+  if (!ctx || !hdr || which < 0 || which > 3) {
     set_error("esc_tile_list_counts: bad argument");
     return ESC_ERR_INVALID;
   }
-  if (which == 2) { // the light lists: cells of every listed light and face
-    if (!ctx->ll_valid || !ctx->ll.hdr) return 0;
+  if (which >= 2) { // the light lists (2: sphere pairs, 3: triangle pairs): cells of every listed light and face
+    const esc::LightLists &LLs = which == 2 ? ctx->ll : ctx->lt;
+    if (!ctx->ll_valid || !LLs.hdr || (which == 2 ? ctx->sg.n_grp : ctx->tg.n_grp) == 0) return 0;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const int Rr = ctx->ll.R, n_faces = ctx->ll.n_listed * 6;
-    int32_t glob_max = 0;
+    const int Rr = LLs.R, n_faces = LLs.n_listed * 6;
+    int32_t glob_max = 0, n_esc = 0, off = 0;
     for (int f = 0; f < n_faces; f++) {
-      int32_t g = 0;
-      HIP_TRY(hipMemcpy(&g, ctx->ll.hdr + (size_t)f * esc::kTileHdrInts, 4, hipMemcpyDeviceToHost));
-      glob_max = std::max(glob_max, g);
+      int32_t g[3] = {0, 0, 0};
+      HIP_TRY(hipMemcpy(g, LLs.hdr + (size_t)f * esc::kTileHdrInts, 12, hipMemcpyDeviceToHost));
+      glob_max = std::max(glob_max, g[0]);
+      n_esc += g[1]; // (kept on face 0 of each light)
+      off |= g[2];
     }
-    const int32_t out[8] = {glob_max, 0, 0, Rr, n_faces * Rr, esc::kLightListCap, esc::kTileGlobalCap, 0};
+    const int32_t out[8] = {glob_max, n_esc, off, Rr, n_faces * Rr, esc::kLightListCap, esc::kTileGlobalCap, 0};
     std::memcpy(hdr, out, sizeof(out));
     const size_t n_cells = (size_t)n_faces * Rr * Rr;
     if (counts)
-      HIP_TRY(hipMemcpy(counts, ctx->ll.cnt, std::min(capacity, n_cells) * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(counts, LLs.cnt, std::min(capacity, n_cells) * 4, hipMemcpyDeviceToHost));
     return (int)n_cells;
   }
   const esc::TileLists &L = which ? ctx->tl : ctx->sl;
@@ -1921,6 +1931,38 @@ int esc_tile_list_counts(esc_context *ctx, int32_t which, int32_t hdr[8], int32_
   if (counts)
     HIP_TRY(hipMemcpy(counts, L.cnt, std::min(capacity, n_tiles) * 4, hipMemcpyDeviceToHost));
   return (int)n_tiles;
+}
+
+int esc_tile_list_ids(esc_context *ctx, int32_t which, int64_t index, int32_t *ids, int32_t capacity) {
+  if (!ctx || !ids || which < 0 || which > 3 || index < 0 || capacity < 1) {
+    set_error("esc_tile_list_ids: bad argument");
+    return ESC_ERR_INVALID;
+  }
+  const int32_t *d_ids = nullptr, *d_cnt = nullptr;
+  int cap = 0;
+  int64_t n = 0;
+  if (which < 2) {
+    const esc::TileLists &L = which ? ctx->tl : ctx->sl;
+    if (!ctx->lists_valid || !L.hdr) return 0;
+    d_ids = L.ids; d_cnt = L.cnt; cap = esc::kTileListCap;
+    n = (int64_t)((ctx->list_key.W + 31) / 32) * ((ctx->list_key.n_local_rows + 3) / 4);
+  } else {
+    const esc::LightLists &L = which == 2 ? ctx->ll : ctx->lt;
+    if (!ctx->ll_valid || !L.hdr) return 0;
+    d_ids = L.ids; d_cnt = L.cnt; cap = esc::kLightListCap;
+    n = (int64_t)L.n_listed * 6 * L.R * L.R;
+  }
+  if (index >= n) {
+    set_error("esc_tile_list_ids: index out of range");
+    return ESC_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int32_t c = 0;
+  HIP_TRY(hipMemcpy(&c, d_cnt + index, 4, hipMemcpyDeviceToHost));
+  const int m = std::min(std::min(c, cap), capacity);
+  if (m > 0) HIP_TRY(hipMemcpy(ids, d_ids + index * cap, (size_t)m * 4, hipMemcpyDeviceToHost));
+  return c;
 }
 
 int esc_tile_rect(const esc_camera *cam, int32_t W, int32_t H, const float centre[3], double radius,

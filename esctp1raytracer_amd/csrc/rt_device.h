@@ -303,10 +303,17 @@ constexpr int kLightListMax = 4;    // lights (sample points) that get lists
 #endif
 constexpr int kLightListRes = ESC_LL_RES;  // cells per cube-face side
 constexpr int kLightListCap = 64;   // pair records per cell (a multiple of 4)
+constexpr int kLightEscCap = 1024;  // triangles per light whose plane (nearly) holds the sample point
+struct alignas(16) LightEsc { // |v . n| <= kp over a cell's directions v = +-e_m + u e_a + w e_b
+  float nx, ny, nz, kp;
+  int32_t pair, pad[3];
+};
 struct LightLists {
-  int32_t *hdr;  // [n_listed * 6][kTileHdrInts]: [0] face-global pair records, [2] off, [8..) their ids
+  int32_t *hdr;  // [n_listed * 6][kTileHdrInts]: [0] face-global pair records, [1] (face 0 of a light:)
+                 // its LightEsc entries, [2] off, [8..) the face-global ids
   int32_t *cnt;  // [n_listed * 6 * R * R]
   int32_t *ids;  // [cells][kLightListCap]
+  LightEsc *esc; // [n_listed][kLightEscCap] (triangle lists only)
   int32_t n_listed; // lights 0 .. n_listed - 1 have lists, built for light_points[point[li]]
   int32_t R;
   int32_t point[kLightListMax];
@@ -494,6 +501,7 @@ struct RenderParams {
   TriGroups tg;                 // triangle groups (both passes)
   TileLists sl, tl;             // primary rays: tile lists of spheres / triangles
   LightLists ll;                // shadow rays: light lists of sphere pair records
+  LightLists lt;                // ... and of triangle pair records
   ShadeQueue sq;                // queue form of the shadow pass (brute force, large scenes)
   HitPlanes hits;               // band-local, n_local_rows * W pixels (scratch owned by the context)
   BvhRef bvh_tri, bvh_sph;      // ESC_STAGE_BVH only

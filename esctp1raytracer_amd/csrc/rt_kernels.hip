@@ -743,7 +743,8 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams p) {
 // TGRP: the scene has triangle groups (rt_device.h TriGroups).  Their sweep needs more registers
 // than 6 waves per SIMD leave (36 B of scratch per lane otherwise), so that variant is built for 5
 // and scenes without triangle groups keep the leaner kernel.
-constexpr int kListServed = 0x40000000; // RepackLds::n_open: this ray's sphere phase ran on light lists
+constexpr int kListServed = 0x40000000;    // RepackLds::n_open: this ray's sphere phase ran on light lists
+constexpr int kTriListServed = 0x20000000; // ... its triangle phase did
 // ---------------------------------------------------------------------------------------
 // The shadow pass of ONE light for the 256 rays of a workgroup, primitives through the scalar cache
 // (main.cpp:772 occlusion(), wave-uniform loops): used by k_shade<SMEM> and by the fused k_frame.
@@ -822,6 +823,23 @@ DEVINL void shadow_sweep_smem(const RenderParams &p, RepackLds &R, int tid, int 
         const RayF rs = make_ray_filter(so, sL, p.shadow_center);
         int n_open = 0;
         if (!last_light) aa[0].orig = reinterpret_cast<const int32_t *>(p.tg.orig); // bias, add 0
+        // a light with one sample point: its triangle light lists (rt_lists.h) -- unless a ray starts
+        // outside the region they were built for, or its cell overflowed
+        bool served = false;
+        const bool outside = far || !(so.x >= p.scene_lo[0] && so.x <= p.scene_hi[0] && so.y >= p.scene_lo[1] &&
+                                      so.y <= p.scene_hi[1] && so.z >= p.scene_lo[2] && so.z <= p.scene_hi[2]);
+        if (p.lt.enabled && li < p.lt.n_listed && n_tri_sweep <= kSegGroupPairs &&
+            __builtin_amdgcn_ballot_w64(aa[0].tb > 0.f && outside) == 0) {
+          const f3 Pl = ld3(p.light_points + 4 * p.lt.point[li]);
+          int n_tests = 0, sw = 0;
+          served = anyhit_tri_light_lists(
+              p.lt, light_list_cell(p.lt, li, Pl, so),
+              SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tg.sorted2_f)},
+              SmemFetch<DevTri>{p.tg.sorted}, 0, so, sL, rt, aa, n_tests, sw);
+          n_swept += sw;
+          if (rr >= 0) R.n_open[rr] = (R.n_open[rr] + (n_tests >> 3)) | (served ? kTriListServed : 0);
+        }
+        if (!served) {
         // k0 sorted slots in = k0 / 8 groups = k0 / kPerSup super-groups = k0 / kPerHyp hyper-groups;
         // two per pair record
         constexpr int kPerSup = kTriGroup * kTriSuper, kPerHyp = kPerSup * kTriHyper;
@@ -837,6 +855,7 @@ DEVINL void shadow_sweep_smem(const RenderParams &p, RepackLds &R, int tid, int 
             rt, far, aa,
             n_open);
         if (rr >= 0 && n_open) R.n_open[rr] += n_open;
+        }
       } else if (in_tris) {
         const V3<V> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
         n_swept += n_here; // upper bound: exits inside a segment are not subtracted
@@ -1113,14 +1132,16 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
           // up to the occluder's (or all), 8 more filter tests per opening this ray needed.
           const int k = a[0].kocc;
           const bool by_tri = k >= 0 && k < p.n_tri;
-          unsigned cnt = tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper * kTriHyper) + 1
-                                                        : p.tg.n_hyp)
-                                    : (unsigned)(by_tri ? k + 1 : p.n_tri);
+          unsigned cnt = (grp_open & kTriListServed)
+                             ? 0u // (its light's triangle lists served it: the batches it was live for)
+                             : tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper * kTriHyper) + 1
+                                                              : p.tg.n_hyp)
+                                          : (unsigned)(by_tri ? k + 1 : p.n_tri);
           // (a ray its light's lists served: the 8-sphere batches it was live for, nothing else)
           if (!by_tri && !(grp_open & kListServed))
             cnt += sph_groups ? (unsigned)(k >= 0 ? ((k - p.n_tri) >> 9) + 1 : p.sg.n_hyp)
                               : (unsigned)(k >= 0 ? k - p.n_tri + 1 : p.n_sph);
-          cnt_lane = cnt + 8u * (unsigned)(grp_open & ~kListServed);
+          cnt_lane = cnt + 8u * (unsigned)(grp_open & ~(kListServed | kTriListServed));
         }
       }
       if (p.shadows && a[0].kocc >= 0) {
@@ -1381,13 +1402,15 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
           n_shadow += 1u;
           const int k = a[0].kocc; // (the counter rules of k_shade)
           const bool by_tri = k >= 0 && k < p.n_tri;
-          unsigned cnt = tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper * kTriHyper) + 1
-                                                        : p.tg.n_hyp)
-                                    : (unsigned)(by_tri ? k + 1 : p.n_tri);
+          unsigned cnt = (grp_open & kTriListServed)
+                             ? 0u // (its light's triangle lists served it: the batches it was live for)
+                             : tri_groups ? (unsigned)(by_tri ? k / (kTriGroup * kTriSuper * kTriHyper) + 1
+                                                              : p.tg.n_hyp)
+                                          : (unsigned)(by_tri ? k + 1 : p.n_tri);
           if (!by_tri && !(grp_open & kListServed))
             cnt += sph_groups ? (unsigned)(k >= 0 ? ((k - p.n_tri) >> 9) + 1 : p.sg.n_hyp)
                               : (unsigned)(k >= 0 ? k - p.n_tri + 1 : p.n_sph);
-          cnt_lane = cnt + 8u * (unsigned)(grp_open & ~kListServed);
+          cnt_lane = cnt + 8u * (unsigned)(grp_open & ~(kListServed | kTriListServed));
         }
         if (p.shadows && a[0].kocc >= 0) {
           t = a[0].tocc; // occlusion() wrote the occluder's t2 through its reference (quirk S3)
@@ -1727,8 +1750,14 @@ extern "C" int esc_launch_tile_lists(const esc::RenderParams *p, hipStream_t str
 // light lists of the shadow pass (rt_lists.h): hdr / cnt zeroed by the caller on this stream
 extern "C" int esc_launch_light_lists(const esc::RenderParams *p, hipStream_t stream) {
   const int n_rec = p->sg.n_grp * (esc::kSphGroup / 2);
-  if (p->ll.n_listed > 0 && n_rec > 0)
+  if (p->ll.enabled && p->ll.n_listed > 0 && n_rec > 0)
     hipLaunchKernelGGL(esc::k_bin_light_pairs, dim3((n_rec + 3) / 4), dim3(256), 0, stream, *p);
+  const int n_trec = p->tg.n_grp * (esc::kTriGroup / 2);
+  if (p->lt.enabled && p->lt.n_listed > 0 && n_trec > 0) {
+    hipLaunchKernelGGL(esc::k_bin_light_tri_pairs, dim3((n_trec + 3) / 4), dim3(256), 0, stream, *p);
+    const int n_cells = p->lt.n_listed * 6 * p->lt.R * p->lt.R;
+    hipLaunchKernelGGL(esc::k_bin_light_tri_escape, dim3((n_cells + 255) / 256), dim3(256), 0, stream, *p);
+  }
   return (int)hipGetLastError();
 }
 

@@ -118,28 +118,32 @@ __global__ void __launch_bounds__(256) k_bin_spheres(const RenderParams p) {
 // every doubtful case (a sliver, a non-finite value) answers yes with no usable normal.
 struct TriEscape {
   bool possible; // the camera is within H of the plane (or nothing can be said)
-  bool bounded;  // nh / beta below are valid: the escape needs |d . nh| < beta
+  bool bounded;  // nh / beta / H below are valid: the escape needs |d . nh| < beta
   f3 nh;         // unit normal
-  float beta;    // tau / |n1| for this camera
+  float beta;    // tau / |n1| for this origin distance
+  float H;       // the origin must lie within H of the plane
 };
-DEVINL TriEscape tri_escape(const DevTri &T, f3 o, float slack_k) {
+// (P) for ray origins with |origin - v0|_1 <= at: beta and H grow with at, so a bound on at gives a
+// bound for every origin it covers.  `pad` out: the slot holds no triangle (all zeros: det == 0).
+DEVINL TriEscape tri_escape_at(const DevTri &T, float at, float slack_k, bool &pad) {
   TriEscape E;
   E.possible = true;
   E.bounded = false;
   E.nh = mk(0.f, 0.f, 0.f);
   E.beta = 0.f;
+  E.H = 0.f;
+  pad = false;
   const float u = 0x1p-24f;
   const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
   if (e1.x == 0.f && e1.y == 0.f && e1.z == 0.f && e2.x == 0.f && e2.y == 0.f && e2.z == 0.f) {
     E.possible = false; // pad slot (or a point): det == 0 exactly, rejected
+    pad = true;
     return E;
   }
-  const f3 tv = o - ld3(T.v0);
   const f3 n1 = cross(e2, e1);
   const float nn = sqrtf(dot(n1, n1));
   const float a1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z);
   const float a2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
-  const float at = (fabsf(tv.x) + fabsf(tv.y)) + fabsf(tv.z);
   const float l1 = sqrtf(dot(e1, e1)), l2 = sqrtf(dot(e2, e2));
   const f3 s3 = (e1 + e2) * (1.f / 3.f);
   const float rho = sqrtf(fmaxf(fmaxf(dot(s3, s3), dot(e1 - s3, e1 - s3)), dot(e2 - s3, e2 - s3)));
@@ -151,12 +155,22 @@ DEVINL TriEscape tri_escape(const DevTri &T, f3 o, float slack_k) {
   if (!(tau < 0.1f * nn)) return E; // |d . n| < 0.1 is part of the argument
   const float ted = (tau + 10.05f * u * p12) * (1.f + 4.f * u);
   const float U = ted + 10.04f * u * at * a2, V = ted + 5.04f * u * at * a1;
-  const float H = (fmaxf(V / l1, U / l2) + at * tau / nn) * (2.f * l1 * l2 / nn) * (1.f / 0.99f);
-  const float h = fabsf(dot(tv, n1)) / nn;
-  E.possible = !(h > H * 1.01f + 0x1p-20f * at); // NaN: yes
+  E.H = (fmaxf(V / l1, U / l2) + at * tau / nn) * (2.f * l1 * l2 / nn) * (1.f / 0.99f);
   E.nh = n1 * (1.f / nn);
   E.beta = tau / nn;
-  E.bounded = (E.nh.x == E.nh.x) && (E.nh.y == E.nh.y) && (E.nh.z == E.nh.z) && (E.beta == E.beta);
+  E.bounded = (E.nh.x == E.nh.x) && (E.nh.y == E.nh.y) && (E.nh.z == E.nh.z) && (E.beta == E.beta) &&
+              (E.H == E.H);
+  return E;
+}
+DEVINL TriEscape tri_escape(const DevTri &T, f3 o, float slack_k) {
+  const f3 tv = o - ld3(T.v0);
+  const float at = (fabsf(tv.x) + fabsf(tv.y)) + fabsf(tv.z);
+  bool pad;
+  TriEscape E = tri_escape_at(T, at, slack_k, pad);
+  if (pad || !E.bounded) return E;
+  const f3 n1 = cross(ld3(T.e2), ld3(T.e1));
+  const float h = fabsf(dot(tv, n1)) / sqrtf(dot(n1, n1));
+  E.possible = !(h > E.H * 1.01f + 0x1p-20f * at); // NaN: yes
   return E;
 }
 
@@ -506,6 +520,298 @@ DEVINL bool anyhit_sph_light_lists(const LightLists &LL, int cell, FetchE rece, 
     }
     for (int k = 0; k < n; k += 4) {
       if (__builtin_amdgcn_ballot_w64(a.tb > 0.f) == 0) return true;
+      batch(ids(k >> 2));
+    }
+    done |= __builtin_amdgcn_ballot_w64(cell == c);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Light lists of TRIANGLE pair records.  For a shadow ray (O, L) towards P that starts inside the
+// grown scene box B (|O - v0|_1 <= at_t := the largest such 1-norm over B's corners), the pre-filter's
+// statement with tau evaluated at at_t (rt_brute.h "Triangle pre-filter", rt_capi.cpp build_tri2pf):
+//   triangle t accepted  ==>  (S_t) the ray's line meets t's plane at X* within k rho_t of t in that plane
+//                             or (E_t) |L . n_t| < beta_t := tau_t(at_t) / (k |n1_t|), and then (P) O lies
+//                             within H_t(at_t) of the plane (tri_escape_at: both grow with at); k: (K) below.
+//  * (S_t) is binned like the tile lists' triangles: the hull of the 12 corners v_i +- rho' e_a +- rho' e_b,
+//    each a ball of radius 2^-20 (at_t + |e1|_1 + |e2|_1) + delta (delta: the line misses P by at most
+//    that, "Light lists" above), projected on each cube face.  TWO-sided: t2 of a nearly parallel ray
+//    can be off by a sixth, so a triangle just beyond P cannot be ruled out by `t2 < |P - O|`; the
+//    double cone of the conic bounds does that by itself (a corner behind the face's plane is
+//    projected through P).  Corners on both sides of a face's plane, or in it: the face's short
+//    list if the triangle's bounding ball reaches the face's directions at all, else nothing.
+//  * (E_t): a ray towards P that is nearly parallel to t's plane and starts within H_t of it has P
+//    within H_t + |P - O| beta_t of the plane.  Per triangle and light that is one comparison; the
+//    few triangles that pass leave an entry (n_t, beta_t) and k_bin_light_tri_escape appends them to
+//    every cell that holds a direction v with |v . n_t| <= beta_t |v| (v . n_t is affine over a cell).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bin_light_tri_pairs(const RenderParams p) {
+  const int j = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63u);
+  const int n_rec = p.tg.n_grp * (kTriGroup / 2);
+  if (j >= n_rec) return;
+  const LightLists LL = p.lt;
+  const double g[3] = {p.shadow_center[0], p.shadow_center[1], p.shadow_center[2]};
+  const double rho_max = (double)p.shadow_rho_max;
+  const int Rr = LL.R, cells_per_face = Rr * Rr;
+  // this lane's corner: triangle h of the pair, corner cn of its 12
+  const int h = (lane % 24) / 12, cn = lane % 12, vi = cn >> 2;
+  const DevTri T = p.tg.sorted[2 * j + h];
+  const f3 e1f = ld3(T.e1), e2f = ld3(T.e2);
+  const bool real = !(e1f.x == 0.f && e1f.y == 0.f && e1f.z == 0.f && e2f.x == 0.f && e2f.y == 0.f && e2f.z == 0.f);
+  const double e1[3] = {e1f.x, e1f.y, e1f.z}, e2[3] = {e2f.x, e2f.y, e2f.z};
+  const double v0[3] = {T.v0[0], T.v0[1], T.v0[2]};
+  double n1[3];
+  cross3(e2, e1, n1);
+  const double nn = sqrt(dot3(n1, n1)), l1 = sqrt(dot3(e1, e1)), l2 = sqrt(dot3(e2, e2));
+  const double s3[3] = {(e1[0] + e2[0]) / 3.0, (e1[1] + e2[1]) / 3.0, (e1[2] + e2[2]) / 3.0};
+  const double q1[3] = {e1[0] - s3[0], e1[1] - s3[1], e1[2] - s3[2]}, q2[3] = {e2[0] - s3[0], e2[1] - s3[1], e2[2] - s3[2]};
+  const double rho = sqrt(fmax(fmax(dot3(s3, s3), dot3(q1, q1)), dot3(q2, q2)));
+  const bool sliver = real && (!(rho > 0x1.4p-10 * fmax(l1, l2)) || !(nn > 0.0) || !(l1 > 0.0));
+  // at_t: the largest |O - v0|_1 over the box of ray origins
+  double at = 0.0;
+  for (int k = 0; k < 3; ++k)
+    at += fmax(fabs(v0[k] - (double)p.scene_lo[k]), fabs(v0[k] - (double)p.scene_hi[k]));
+  const double a12 = (fabs(e1[0]) + fabs(e1[1]) + fabs(e1[2])) + (fabs(e2[0]) + fabs(e2[1]) + fabs(e2[2]));
+  // Statement (K) of rt_brute.h trades the two halves: with the escape threshold tau_t / k an accepted
+  // hit lies within 0.9375 k rho_t + 4u emax <= k rho_t of its triangle (k >= 64u emax / rho_t, i.e.
+  // k >= 0.004 for anything that is not a sliver), and the escape needs the origin within H_t(tau_t / k)
+  // of the plane.  Each triangle takes, per light, the SMALLEST k of 1/8, 1/4, 1/2, 1 for which no ray
+  // towards that light can take the escape at all (P further than H + Lmax beta from the plane): an
+  // eighth of the dilation for nearly every triangle; a triangle that fails even at k = 1 (the
+  // light sits in its plane) leaves an escape entry at k = 1.
+  for (int li = 0; li < LL.n_listed; ++li) {
+    const double P[3] = {p.light_points[4 * LL.point[li]], p.light_points[4 * LL.point[li] + 1],
+                         p.light_points[4 * LL.point[li] + 2]};
+    const double delta = 0x1p-20 * (rho_max + fabs(P[0] - g[0]) + fabs(P[1] - g[1]) + fabs(P[2] - g[2]));
+    const double slack = 0x1p-20 * (at + a12) + delta + 0x1p-60;
+    double c0[3], ctr[3]; // v0 and the centroid relative to P
+    for (int k = 0; k < 3; ++k) {
+      c0[k] = v0[k] - P[k];
+      ctr[k] = c0[k] + s3[k];
+    }
+    double lmax2 = 0.0; // the longest ray towards P from inside the box
+    for (int k = 0; k < 3; ++k) {
+      const double d = fmax(fabs(P[k] - (double)p.scene_lo[k]), fabs(P[k] - (double)p.scene_hi[k]));
+      lmax2 += d * d;
+    }
+    const double hP = real && nn > 0.0 ? fabs(dot3(c0, n1)) / nn : 0.0;
+    double kK = 1.0;
+    bool pad_slot, flagged = true;
+    TriEscape E = tri_escape_at(T, (float)(at * (1.0 + 0x1p-20)), 1.f, pad_slot);
+    double kp = (double)E.beta * 1.0001 + 0x1p-20;
+    for (int tr = 0; tr < 4 && real; ++tr) {
+      const double kc = 0.125 * (double)(1 << tr);
+      const TriEscape Ec = tri_escape_at(T, (float)(at * (1.0 + 0x1p-20)), (float)kc, pad_slot);
+      const double kpc = (double)Ec.beta * 1.0001 + 0x1p-20;
+      const bool fl = !Ec.bounded || !(hP > (double)Ec.H * 1.01 + sqrt(lmax2) * kpc + slack);
+      if (!fl || tr == 3) {
+        kK = kc;
+        E = Ec;
+        kp = kpc;
+        flagged = fl;
+        break;
+      }
+    }
+    const double rp = kK * rho * (1.0 + 1e-5) + slack;
+    const double cdist = sqrt(dot3(ctr, ctr)), ball = rho + 1.5 * rp; // holds the 12 corners' balls
+    // a pair with a sliver, a triangle without usable bounds, or P (all but) inside a bounding ball:
+    // every direction of every face
+    const bool everywhere = real && (sliver || (E.possible && !E.bounded) || !(cdist > ball * 1.001));
+    // (E_t) + (P): can ANY ray towards P from inside the box take the escape?  P within H + Lmax beta
+    if (real && !everywhere && E.bounded && cn == 0 && lane < 24) {
+      if (flagged) {
+        int32_t *hdr0 = LL.hdr + (size_t)(li * 6) * kTileHdrInts;
+        const int slot = atomicAdd(&hdr0[1], 1);
+        if (slot < kLightEscCap) {
+          LightEsc X;
+          X.nx = E.nh.x;
+          X.ny = E.nh.y;
+          X.nz = E.nh.z;
+          X.kp = (float)kp;
+          X.pair = j;
+          X.pad[0] = X.pad[1] = X.pad[2] = 0;
+          LL.esc[(size_t)li * kLightEscCap + slot] = X;
+        }
+      }
+    }
+    double ea[3] = {0, 0, 0}, eb[3] = {0, 0, 0};
+    if (real && !sliver) {
+      for (int k = 0; k < 3; ++k) ea[k] = e1[k] / l1;
+      cross3(n1, ea, eb);
+      for (int k = 0; k < 3; ++k) eb[k] /= nn;
+    }
+    const double sa = (cn & 1) ? rp : -rp, sb = (cn & 2) ? rp : -rp;
+    double pt[3];
+    for (int k = 0; k < 3; ++k)
+      pt[k] = c0[k] + (vi == 1 ? e1[k] : 0.0) + (vi == 2 ? e2[k] : 0.0) + sa * ea[k] + sb * eb[k];
+    const unsigned long long any_everywhere = __builtin_amdgcn_ballot_w64(everywhere);
+    for (int face = 0; face < 6; ++face) {
+      int32_t *hdr = LL.hdr + (size_t)(li * 6 + face) * kTileHdrInts;
+      int m, ia, ib;
+      double sign;
+      light_face_axes(face, m, ia, ib, sign);
+      bool face_global = any_everywhere != 0;
+      int rect[2][4]; // per triangle of the pair: u0, u1, w0, w1 (cells), u0 > u1: none
+      rect[0][0] = rect[1][0] = 1;
+      rect[0][1] = rect[1][1] = 0;
+      if (!face_global) {
+        const CamD cam = light_face_frame(P, face);
+        double e[4], depth = 0.0;
+        const bool bounded = sphere_pixel_extent(cam, Rr + 1, Rr + 1, pt, slack, e, &depth, 1e-3);
+        // per triangle of the pair: all 12 corners bounded and on one side of the face's plane?
+        for (int hh = 0; hh < 2; ++hh) {
+          const unsigned long long mine = 0xFFFull << (12 * hh); // lanes 0..11 / 12..23 hold its corners
+          const unsigned long long is_real = __builtin_amdgcn_ballot_w64(real) & mine;
+          if (!is_real) continue;
+          const unsigned long long nb = __builtin_amdgcn_ballot_w64(!bounded) & mine;
+          const unsigned long long fr = __builtin_amdgcn_ballot_w64(depth > 0.0) & mine;
+          if (nb == 0 && (fr == 0 || fr == mine)) {
+            // union of this triangle's corner extents (lanes outside `mine` contribute nothing)
+            const bool in = (lane < 24) && (lane / 12 == hh);
+            double x0 = in ? e[0] : 1e300, x1 = in ? e[1] : -1e300, y0 = in ? e[2] : 1e300, y1 = in ? e[3] : -1e300;
+            for (int off = 32; off > 0; off >>= 1) {
+              x0 = fmin(x0, __shfl_xor(x0, off));
+              x1 = fmax(x1, __shfl_xor(x1, off));
+              y0 = fmin(y0, __shfl_xor(y0, off));
+              y1 = fmax(y1, __shfl_xor(y1, off));
+            }
+            rect[hh][0] = max(0, (int)floor(x0));
+            rect[hh][1] = min(Rr - 1, (int)floor(x1));
+            rect[hh][2] = max(0, (int)floor(y0));
+            rect[hh][3] = min(Rr - 1, (int)floor(y1));
+            if (rect[hh][2] > rect[hh][3]) rect[hh][0] = 1, rect[hh][1] = 0; // seen through other faces only
+          } else {
+            // cut by the face's plane: relevant only if its bounding ball reaches the face's
+            // directions (within acos(1 / sqrt 3) of the axis), seen from either side of P
+            const int src = 12 * hh; // a lane that holds this triangle's numbers
+            const double cd = __shfl(cdist, src), bl = __shfl(ball, src), cm = __shfl(ctr[m], src);
+            const double ang = acos(fmax(-1.0, fmin(1.0, fabs(cm) / cd)));
+            const double phi = asin(fmin(1.0, bl / cd));
+            if (!(ang > 0.95532 + phi + 1e-6)) face_global = true;
+          }
+        }
+      }
+      if (face_global) {
+        if (lane == 0) {
+          const int slot = atomicAdd(&hdr[0], 1);
+          if (slot < kTileGlobalCap) hdr[8 + slot] = j;
+        }
+        continue;
+      }
+      // the two triangles' rectangles: one append when they touch (neighbours in space mostly do),
+      // two when they lie apart (one in front of the face's plane, one behind it: their images are
+      // at opposite ends of the face, and a union would cover everything in between)
+      const bool v0r = rect[0][0] <= rect[0][1], v1r = rect[1][0] <= rect[1][1];
+      if (v0r && v1r && rect[0][0] <= rect[1][1] + 1 && rect[1][0] <= rect[0][1] + 1 &&
+          rect[0][2] <= rect[1][3] + 1 && rect[1][2] <= rect[0][3] + 1) {
+        rect[0][0] = min(rect[0][0], rect[1][0]);
+        rect[0][1] = max(rect[0][1], rect[1][1]);
+        rect[0][2] = min(rect[0][2], rect[1][2]);
+        rect[0][3] = max(rect[0][3], rect[1][3]);
+        rect[1][0] = 1;
+        rect[1][1] = 0;
+      }
+      const size_t cell0 = (size_t)(li * 6 + face) * cells_per_face;
+      for (int hh = 0; hh < 2; ++hh) {
+        if (rect[hh][0] > rect[hh][1]) continue;
+        const int nx = rect[hh][1] - rect[hh][0] + 1, n = nx * (rect[hh][3] - rect[hh][2] + 1);
+        for (int k = lane; k < n; k += 64) {
+          const size_t cell = cell0 + (size_t)(rect[hh][2] + k / nx) * Rr + rect[hh][0] + k % nx;
+          const int slot = atomicAdd(&LL.cnt[cell], 1);
+          if (slot < kLightListCap) LL.ids[cell * kLightListCap + slot] = j;
+        }
+      }
+    }
+  }
+}
+
+// (E_t): one thread per cell against the light's entries
+__global__ void __launch_bounds__(256) k_bin_light_tri_escape(const RenderParams p) {
+  const LightLists LL = p.lt;
+  const int Rr = LL.R, cells_per_face = Rr * Rr;
+  const int cell = blockIdx.x * 256 + (int)threadIdx.x;
+  if (cell >= LL.n_listed * 6 * cells_per_face) return;
+  const int li = cell / (6 * cells_per_face), face = (cell / cells_per_face) % 6;
+  const int cw = (cell % cells_per_face) / Rr, cu = cell % Rr;
+  int32_t *hdr0 = LL.hdr + (size_t)(li * 6) * kTileHdrInts;
+  const int n_esc = hdr0[1];
+  if (n_esc == 0) return;
+  if (n_esc > kLightEscCap) {
+    LL.hdr[(size_t)(li * 6 + face) * kTileHdrInts + 2] = 1; // too many: this light's rays take the sweep
+    return;
+  }
+  int m, ia, ib;
+  double sign;
+  light_face_axes(face, m, ia, ib, sign);
+  // directions of the cell: v = sign e_m + u e_a + w e_b, (u, w) in the cell's square grown a little
+  const double u0 = 2.0 * (cu - 1e-3) / Rr - 1.0, u1 = 2.0 * (cu + 1.0 + 1e-3) / Rr - 1.0;
+  const double w0 = 2.0 * (cw - 1e-3) / Rr - 1.0, w1 = 2.0 * (cw + 1.0 + 1e-3) / Rr - 1.0;
+  const double um = fmax(fabs(u0), fabs(u1)), wm = fmax(fabs(w0), fabs(w1));
+  const double vmax = sqrt(1.0 + um * um + wm * wm) * (1.0 + 1e-9);
+  for (int k = 0; k < n_esc; ++k) {
+    const LightEsc X = LL.esc[(size_t)li * kLightEscCap + k];
+    const double nv[3] = {X.nx, X.ny, X.nz};
+    const double fA = sign * nv[m], fU = nv[ia], fW = nv[ib];
+    const double lo = fA + fmin(u0 * fU, u1 * fU) + fmin(w0 * fW, w1 * fW);
+    const double hi = fA + fmax(u0 * fU, u1 * fU) + fmax(w0 * fW, w1 * fW);
+    const double wd = (double)X.kp * vmax + 1e-12;
+    if ((lo <= wd && hi >= -wd) || !(fA == fA)) {
+      const int slot = atomicAdd(&LL.cnt[cell], 1);
+      if (slot < kLightListCap) LL.ids[(size_t)cell * kLightListCap + slot] = X.pair;
+    }
+  }
+}
+
+// Shadow rays of a wave through the triangle light lists (the scheme of anyhit_sph_light_lists): four
+// pair records per step through the triangle filter, flagged pairs through the reference arithmetic.
+// `far` rays (outside the region the FILTER's margins hold for) make the wave take the sweep.
+template <typename FetchF, typename FetchE>
+DEVINL bool anyhit_tri_light_lists(const LightLists &LL, int cell, FetchF recf, FetchE rece, int base, f3 o, f3 L,
+                                   const RayTF &rf, Any (&a)[1], int &n_tests, int &swept) {
+  const V3<float> ov[1] = {{o.x, o.y, o.z}}, Lv[1] = {{L.x, L.y, L.z}};
+  auto level2 = [&](int k0, int k1) { // pair records k0, k1 = sorted triangles 2 k0, 2 k0 + 1, 2 k1, 2 k1 + 1
+    const TriPairF R[2] = {recf(k0), recf(k1)};
+    v2f A[2], B[2], C[2];
+    tripair2_any_filter_pk(R, rf, A, B, C);
+    const int f0 = tri_flags(A[0], B[0], C[0], -1), f1 = tri_flags(A[1], B[1], C[1], -1);
+    if (ANY_LANE_RARE(max(f0, f1) >= 0)) {
+      if (__builtin_amdgcn_ballot_w64(f0 >= 0)) {
+        test_tri_any<float, 1>(rece(2 * k0), base + 2 * k0, ov, Lv, a);
+        test_tri_any<float, 1>(rece(2 * k0 + 1), base + 2 * k0 + 1, ov, Lv, a);
+      }
+      if (__builtin_amdgcn_ballot_w64(f1 >= 0)) {
+        test_tri_any<float, 1>(rece(2 * k1), base + 2 * k1, ov, Lv, a);
+        test_tri_any<float, 1>(rece(2 * k1 + 1), base + 2 * k1 + 1, ov, Lv, a);
+      }
+    }
+  };
+  const int cells_per_face = LL.R * LL.R;
+  const ListPtr cnt = (ListPtr)(uintptr_t)LL.cnt;
+  unsigned long long done = 0;
+  for (;;) {
+    const unsigned long long todo = __builtin_amdgcn_ballot_w64(a[0].tb > 0.f) & ~done;
+    if (todo == 0) return true;
+    const int leader = __builtin_ctzll(todo);
+    const int c = __builtin_amdgcn_readlane(cell, leader);
+    const ListPtr hdr = (ListPtr)(uintptr_t)(LL.hdr + (size_t)(c / cells_per_face) * kTileHdrInts);
+    const int n_glob = hdr[0], n = cnt[c];
+    if (n_glob > kTileGlobalCap || n > kLightListCap || hdr[2] != 0) return false;
+    const SmemFetch<DevIdx4> glob{reinterpret_cast<const DevIdx4 *>(LL.hdr + (size_t)(c / cells_per_face) * kTileHdrInts + 8)};
+    const SmemFetch<DevIdx4> ids{reinterpret_cast<const DevIdx4 *>(LL.ids + (size_t)c * kLightListCap)};
+    auto batch = [&](const DevIdx4 &I) { // four pair records = 8 triangles
+      n_tests += (a[0].tb > 0.f) ? 8 : 0;
+      swept += 8;
+      level2(I.v[0], I.v[1]);
+      level2(I.v[2], I.v[3]);
+    };
+    for (int k = 0; k < n_glob; k += 4) {
+      if (__builtin_amdgcn_ballot_w64(a[0].tb > 0.f) == 0) return true;
+      batch(glob(k >> 2));
+    }
+    for (int k = 0; k < n; k += 4) {
+      if (__builtin_amdgcn_ballot_w64(a[0].tb > 0.f) == 0) return true;
       batch(ids(k >> 2));
     }
     done |= __builtin_amdgcn_ballot_w64(cell == c);

@@ -441,6 +441,11 @@ int esc_tile_band(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, i
 int esc_tile_list_counts(esc_context *ctx, int32_t which, int32_t hdr[8], int32_t *counts,
                          size_t capacity);
 
+/* ... and the entries of ONE tile / cell (`index` in the order of esc_tile_list_counts): slots of
+ * the group-sorted tables (which = 0, 1) or pair records (2, 3).  Returns the appended count (the
+ * list holds min(count, capacity of the list) entries; at most `capacity` are copied). */
+int esc_tile_list_ids(esc_context *ctx, int32_t which, int64_t index, int32_t *ids, int32_t capacity);
+
 /* Host only, for inspection and tests: the spatial order the groups are cut from (k-d median
  * splits over the points; csrc/rt_device.h SphGroups / TriGroups).  xyz holds 3 floats per point;
  * order receives a permutation of 0 .. count-1 whose consecutive runs of `run`, `big` and `huge`

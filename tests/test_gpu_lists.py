@@ -47,7 +47,7 @@ def both_ways(esc, renderer, d, eye, look, W, H, what, expect_lists=True, **kw):
     renderer.reset_counters()
     gpu = renderer.render(cam, W, H, **kw)
     c_lists = renderer.counters()
-    stats = [renderer.tile_lists(w) for w in (0, 1, 2)]
+    stats = [renderer.tile_lists(w) for w in (0, 1, 2, 3)]
     assert_bit_equal(gpu, ref, what + "/lists")
     off = esc.ESC_RENDER_NO_TILE_LISTS | esc.ESC_RENDER_NO_LIGHT_LISTS
     renderer.reset_counters()
@@ -328,7 +328,7 @@ def test_lists_equal_sweep_full_size(esc, renderer, config, W, H):
     renderer.reset_counters()
     renderer.render_rows(cam, W, H, 0, H, out_f32=a, out_u8=a8)
     ca = renderer.counters()
-    st = [renderer.tile_lists(w) for w in (0, 1, 2)]
+    st = [renderer.tile_lists(w) for w in (0, 1, 2, 3)]
     renderer.reset_counters()
     renderer.render_rows(cam, W, H, 0, H, out_f32=b, out_u8=b8,
                          flags=esc.ESC_RENDER_NO_TILE_LISTS | esc.ESC_RENDER_NO_LIGHT_LISTS)

@@ -17,7 +17,7 @@ cam = esc.Camera.for_image(*esc.synthetic_view(), W, H)
 buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
 r.render_rows(cam, W, H, 0, H, out_f32=buf)
 r.synchronize()
-for which, name in ((0, "spheres"), (1, "triangles"), (2, "light-list cells (pair records)")):
+for which, name in ((0, "spheres"), (1, "triangles"), (2, "light-list cells (sphere pairs)"), (3, "light-list cells (triangle pairs)")):
     L = r.tile_lists(which)
     if L is None:
         print(cfg, name, ": no lists")
@@ -32,3 +32,8 @@ for which, name in ((0, "spheres"), (1, "triangles"), (2, "light-list cells (pai
     rows = c.mean(axis=1)
     print("  mean per tile row, 16 bands top->bottom of the band:", [round(float(x), 1) for x in
                                                                      [rows[i * len(rows) // 16:(i + 1) * len(rows) // 16].mean() for i in range(16)]])
+    if which >= 2:
+        R = L["tiles_x"]
+        faces = c.reshape(-1, R, R)
+        print("  per face (+x -x +y -y +z -z per light): mean", [round(float(f.mean()), 2) for f in faces],
+              "max", [int(f.max()) for f in faces])
