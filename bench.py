@@ -446,8 +446,10 @@ def main():
             acc[0] += ms[0]
             acc[1] += ms[1]
         kernel_split = {"k_primary_ms": acc[0] / n_split, "k_shade_ms": acc[1] / n_split,
-                        "note": "k_shade_ms = everything after k_primary: the fused k_shade, or "
-                                "k_shadow_setup + k_anyhit_segment x segments + k_shade_finish"}
+                        "note": "the TWO-kernel variant of the frame (ESC_RENDER_TIME_KERNELS records an "
+                                "event between the halves, so it renders with k_primary + k_shade instead "
+                                "of the one-kernel k_frame the timed steps use: a few per cent slower in "
+                                "total); k_shade_ms = everything after k_primary"}
 
     # `linear`: the same frame with every (ray, primitive) pair visited in the reference's index
     # order (ESC_RENDER_INDEX_ORDER: no groups, no re-ordered last light) -- BASELINE's "brute-force
@@ -650,9 +652,10 @@ def main():
                 "anyhit_tests_per_frame_index_order": anyhit_index_order,
                 "shadow_lane_efficiency": (anyhit / lane_tests) if lane_tests else None,
             },
-            "kernel": {"name": "one frame = k_primary + the shading kernels (fused k_shade; or, for "
-                               "long linearly swept lists, k_shadow_setup + k_anyhit_segment per "
-                               "segment + k_shade_finish per light), back to back on one stream"
+            "kernel": {"name": ("one frame = k_frame (closest hit and shading of a 64x8 tile in one kernel; "
+                                "linear sweeps of long lists: k_primary + k_shadow_setup + k_anyhit_segment per "
+                                "segment + k_shade_finish per light), HIP events on the launch stream around "
+                                "each frame")
                                + ("" if world == 1 else "; N>1: two frames are in flight on two "
                                   "streams, so this duration includes time shared with the other frame"),
                        "avg_ms": kernel_ms,

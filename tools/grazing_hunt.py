@@ -19,6 +19,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r = esc.Renderer(0)
 W, H = 256, 96
 found = 0
+with_hits = 0
+grazing_hits = 0
 for it in range(n):
     dist = 10.0 ** rng.uniform(1.0, 2.7)          # 10 .. 500 units away
     size = 10.0 ** rng.uniform(-1.0, 0.7)         # triangles of 0.1 .. 5 units
@@ -41,10 +43,12 @@ for it in range(n):
     a = r.render(cam, W, H, shadows=bool(it % 2))
     b = r.render(cam, W, H, shadows=bool(it % 2), stage=esc.ESC_STAGE_BVH, flags=esc.ESC_RENDER_BVH_HEURISTIC_PADS)
     nd = int((a.view(np.uint32) != b.view(np.uint32)).any(axis=2).sum())
+    c = r.counters()
+    with_hits += 1 if a.any() else 0
     if nd:
         found += 1
         print(f"DIFFERENCE it={it} dist={dist:.3g} size={size:.3g} eye={eye} pixels={nd} hit pixels={int((a.sum(axis=2) > 0).sum())}")
         if found <= 3:
             np.savez(os.path.join(ROOT, "gpurun_out", f"grazing_case_{it}.npz"), tris=np.array(tris, np.float32),
                      eye=np.array(eye), look=np.array(look), dist=dist, W=W, H=H)
-print(f"{n} scenes, {found} with a tree-vs-proven difference")
+print(f"{n} scenes ({with_hits} with lit pixels), {found} with a tree-vs-proven difference")
