@@ -1992,15 +1992,17 @@ int esc_tile_band(const esc_camera *cam, int32_t W, int32_t H, int32_t tile_x, i
   camera_params(cam, W, H, p);
   const esc::CamD c = esc::cam_frame(p);
   if (!c.ok) return 1;
-  double st[4], pmax;
-  esc::tile_st_rect(p, c, tile_x, row, st, pmax);
-  if (!(pmax == pmax)) return 1;
   double fA = 0, fH = 0, fV = 0;
   for (int j = 0; j < 3; ++j) {
     fA += ((double)p.llc[j] - c.o[j]) * (double)normal[j];
     fH += (double)p.horizontal[j] * (double)normal[j];
     fV += (double)p.vertical[j] * (double)normal[j];
   }
+  int tx0 = 0, tx1 = -1; // what k_bin_tri_escape does for this row
+  if (!esc::band_row_tiles(p, c, row, (W + 31) / 32, fA, fH, fV, kp, tx0, tx1)) return 1;
+  if (tile_x < tx0 || tile_x > tx1) return 0;
+  double st[4], pmax;
+  esc::tile_st_rect(p, c, tile_x, row, st, pmax);
   return esc::tile_band_hit(st, pmax, fA, fH, fV, kp) ? 1 : 0;
 }
 

@@ -178,4 +178,37 @@ HDINL bool tile_band_hit(const double st[4], double pmax, double fA, double fH, 
   return lo <= w && hi >= -w; // false for NaN: the caller must have ruled those out
 }
 
+// The tiles [tx0, tx1] of the tile row that holds image rows [h, h + 4) which a ray with |p . n| <= kp |p|
+// can fall into, p . n = fA + s fH + t fV (affine in the image-plane coordinates): over the row's t range
+// the band is an interval of s.  Returns 1 (tx0 <= tx1: those tiles; tx0 > tx1: none) or 0 (nothing can
+// be said: the caller switches the lists off).
+HDINL int band_row_tiles(const RenderParams &p, const CamD &cam, int h, int tiles_x, double fA, double fH,
+                         double fV, double kp, int &tx0, int &tx1) {
+  double st[4], pmax_l, pmax_r;
+  tile_st_rect(p, cam, 0, h, st, pmax_l);
+  const double t0 = st[2], t1 = st[3];
+  tile_st_rect(p, cam, tiles_x - 1, h, st, pmax_r);
+  const double pmax = fmax(pmax_l, pmax_r); // |p| is convex: over the row strip it peaks at an end
+  const double w = kp * pmax + 1e-12 * (fabs(fA) + fabs(fH) + fabs(fV));
+  const double g_lo = fA + fmin(t0 * fV, t1 * fV), g_hi = fA + fmax(t0 * fV, t1 * fV);
+  if (!(pmax == pmax) || !(pmax < 1e150) || !(w == w) || !(g_lo == g_lo) || !(g_hi == g_hi)) return 0;
+  // some t in the row with |g(t) + s fH| <= w  <=>  s fH in [-w - g_hi, w - g_lo]
+  const double lo = -w - g_hi, hi = w - g_lo;
+  const double W1 = (double)(p.W - 1);
+  const double pw = 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1; // (tile_st_rect's growth)
+  tx0 = 0;
+  tx1 = tiles_x - 1;
+  if (fabs(fH) * (W1 + 2.0 * pw) > 1e-280) {
+    const double sa = lo / fH, sb = hi / fH;
+    const double wa = fmin(sa, sb) * W1 - pw - 31.0, wb = fmax(sa, sb) * W1 + pw; // tile tx holds [32 tx, 32 tx + 31]
+    if (!(wa == wa) || !(wb == wb)) return 0;
+    tx0 = (int)fmax(0.0, fmin(1e9, ceil(wa / 32.0))); // 32 tx + 31 >= the band's first pixel
+    tx1 = (int)fmin((double)(tiles_x - 1), fmax(-1.0, floor(wb / 32.0)));
+  } else if (!(lo <= 0.0 && hi >= 0.0)) {
+    tx0 = 1; // the band is (all but) horizontal and misses this row
+    tx1 = 0;
+  }
+  return 1;
+}
+
 } // namespace esc

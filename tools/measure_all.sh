@@ -18,7 +18,8 @@ for c in c3 c4; do
 done
 python - <<'PY' > $O/build_times.txt 2>&1
 import time, torch, esctp1raytracer_amd as esc
-r = esc.Renderer(0)
+st = torch.cuda.Stream()
+r = esc.Renderer(0, stream=st)   # events below are recorded on the stream the kernels run on
 for cfg, W, H in (("c3", 3840, 2160), ("c4", 3840, 2160), ("c5", 7680, 4320)):
     sc = esc.Scene.synthetic(cfg)
     r.upload(sc); r.synchronize()
@@ -27,14 +28,14 @@ for cfg, W, H in (("c3", 3840, 2160), ("c4", 3840, 2160), ("c5", 7680, 4320)):
     cam = esc.Camera.for_image(eye, look, W, H)
     buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
     e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    e[0].record(); r.render_rows(cam, W, H, 0, H, out_f32=buf); e[1].record()   # builds every list
-    r.render_rows(cam, W, H, 0, H, out_f32=buf); e[2].record(); r.synchronize()
+    e[0].record(st); r.render_rows(cam, W, H, 0, H, out_f32=buf); e[1].record(st)   # builds every list
+    r.render_rows(cam, W, H, 0, H, out_f32=buf); e[2].record(st); r.synchronize()
     first, steady = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
     mv = []
     for i in range(10):  # a camera that moves every frame: per-camera tables + tile lists rebuilt
         c2 = esc.Camera.for_image((eye[0] + 0.01 * (i + 1), eye[1], eye[2]), look, W, H)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); r.render_rows(c2, W, H, 0, H, out_f32=buf); b.record(); r.synchronize()
+        a.record(st); r.render_rows(c2, W, H, 0, H, out_f32=buf); b.record(st); r.synchronize()
         mv.append(a.elapsed_time(b))
     mv.sort()
     print(f"{cfg}: upload (stage + commit incl. group build) {1e3 * (t1 - t0):.1f} ms; first frame (per-camera tables, "
