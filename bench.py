@@ -99,8 +99,8 @@ def counter_view(kern):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c4", help="c2|c3|c4|c5 (BASELINE.json configs 2-5)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -115,10 +115,12 @@ def parse():
                          "TIMED path (what tools/profile.sh wraps for the `linear` counters)")
     ap.add_argument("--linear-steps", type=int, default=-1,
                     help="frames of the `linear` leg (default: min(steps, 5); 0 = skip)")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="timed steps call esc_render_strips (parameter block + kernel launches per "
-                         "frame) instead of replaying a recorded frame (esc_frame_record: one "
-                         "hipGraphLaunch per frame)")
+    ap.add_argument("--graph", action="store_true",
+                    help="timed steps replay a recorded frame (esc_frame_record: one hipGraphLaunch "
+                         "per frame) instead of calling esc_render_strips (parameter block + kernel "
+                         "launches per frame).  Off by default: a frame is ONE kernel, the plain call "
+                         "costs ~6 us of host time, and graph replays run ~20 us per frame slower on "
+                         "the GPU back to back (`host` reports both)")
     ap.add_argument("--no-accel", action="store_true",
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
     ap.add_argument("--profile-run", action="store_true",
@@ -349,10 +351,10 @@ def main():
         renderers.append(rb)
         streams.append(stb)
 
-    # the frame of each (renderer, buffer) pair recorded once (HIP graph): a timed step is then ONE
-    # host call; --no-graph keeps the plain entry
+    # --graph: the frame of each (renderer, buffer) pair recorded once (HIP graph): a timed step is
+    # then ONE host call
     recorded = [None] * n_buf
-    if not a.no_graph:
+    if a.graph:
         for b in range(n_buf):
             with torch.cuda.stream(streams[b % len(streams)]):
                 recorded[b] = renderers[b % len(renderers)].record_strips(
@@ -518,7 +520,7 @@ def main():
         host = {"what": "host microseconds per frame, K frames enqueued without waiting: `plain` = "
                         "esc_render_strips (parameter block + one launch per kernel), `recorded` = "
                         "esc_frame_launch (one hipGraphLaunch); through the Python binding",
-                "timed_steps_use": "plain" if a.no_graph else "recorded"}
+                "timed_steps_use": "recorded" if a.graph else "plain"}
         share = torch.zeros(multigpu.max_local_rows(H, 8, S) * W * 3, dtype=ch_dtype, device=dev)
         for label, fs, stride, out in (("whole_frame", 0, 1, local[0]), ("rank_0_of_8", 0, 8, share)):
             kw = dict(out_f32=None if use_u8 else out, out_u8=out if use_u8 else None, strip_rows=S,
@@ -537,17 +539,24 @@ def main():
                     r.render_strips(cam, W, H, fs, stride, **kw)
                 t_plain = (time.perf_counter() - th) / n_rep * 1e6
                 r.synchronize()
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record(st)
-                for _ in range(n_rep):
-                    rec.launch()
-                ev1.record(st)
-                r.synchronize()
+                gpu_us = {}
+                for form in ("recorded", "plain"):
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record(st)
+                    for _ in range(n_rep):
+                        if form == "recorded":
+                            rec.launch()
+                        else:
+                            r.render_strips(cam, W, H, fs, stride, **kw)
+                    ev1.record(st)
+                    r.synchronize()
+                    gpu_us[form] = ev0.elapsed_time(ev1) / n_rep * 1e3
                 rec.close()
             host[label] = {"plain_us_per_frame": t_plain, "recorded_us_per_frame": t_rec,
-                           "gpu_us_per_frame_back_to_back": ev0.elapsed_time(ev1) / n_rep * 1e3}
-        host["host_us_per_frame"] = host["whole_frame"]["plain_us_per_frame" if a.no_graph
-                                                        else "recorded_us_per_frame"]
+                           "gpu_us_per_frame_back_to_back": gpu_us["plain"],
+                           "gpu_us_per_frame_back_to_back_recorded": gpu_us["recorded"]}
+        host["host_us_per_frame"] = host["whole_frame"]["recorded_us_per_frame" if a.graph
+                                                        else "plain_us_per_frame"]
 
     # N=1, for information only (the headline stays one frame at a time so that kernel.avg_ms is an
     # undisturbed duration): the same K frames with two in flight on two streams, which fills the
