@@ -1459,26 +1459,38 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
     if (want) {
       const int tiles_x = (W + 31) / 32, tile_rows = (n_local_rows + 3) / 4;
       const size_t n_tiles = (size_t)tiles_x * tile_rows;
-      if (n_tiles > ctx->list_tiles_cap || !ctx->sl.hdr) {
+      // headers and counts exist for both kinds; the slot arrays (kTileListCap ints per tile: 0.5 GB
+      // for an 8K frame) only for the kinds this scene has
+      const bool need_ids[2] = {p.sg.n_grp > 0, p.tg.n_grp > 0};
+      const bool grow = n_tiles > ctx->list_tiles_cap || !ctx->sl.hdr;
+      if (grow || (need_ids[0] && !ctx->sl.ids) || (need_ids[1] && !ctx->tl.ids)) {
         HIP_TRY(hipStreamSynchronize(ctx->stream)); // an earlier frame may still read the old lists
-        void *old[] = {ctx->sl.hdr, ctx->sl.cnt, ctx->sl.ids, ctx->tl.hdr, ctx->tl.cnt, ctx->tl.ids,
-                       ctx->tl.esc};
-        for (void *q : old)
-          if (q) HIP_TRY(hipFree(q));
-        ctx->sl = esc::TileLists{};
-        ctx->tl = esc::TileLists{};
-        ctx->list_tiles_cap = 0;
-        ctx->lists_valid = false;
         int rc;
-        for (esc::TileLists *L : {&ctx->sl, &ctx->tl}) {
-          if ((rc = alloc_dev(L->hdr, (size_t)esc::kTileHdrInts))) return rc;
-          if ((rc = alloc_dev(L->cnt, n_tiles))) return rc;
-          if ((rc = alloc_dev(L->ids, n_tiles * esc::kTileListCap))) return rc;
-          // slots past a count are read in whole batches of 4: zeros are valid slots
-          HIP_TRY(hipMemsetAsync(L->ids, 0, n_tiles * esc::kTileListCap * 4, ctx->stream));
+        if (grow) {
+          void *old[] = {ctx->sl.hdr, ctx->sl.cnt, ctx->sl.ids, ctx->tl.hdr, ctx->tl.cnt, ctx->tl.ids,
+                         ctx->tl.esc};
+          for (void *q : old)
+            if (q) HIP_TRY(hipFree(q));
+          ctx->sl = esc::TileLists{};
+          ctx->tl = esc::TileLists{};
+          ctx->list_tiles_cap = 0;
+          ctx->lists_valid = false;
+          for (esc::TileLists *L : {&ctx->sl, &ctx->tl}) {
+            if ((rc = alloc_dev(L->hdr, (size_t)esc::kTileHdrInts))) return rc;
+            if ((rc = alloc_dev(L->cnt, n_tiles))) return rc;
+          }
+          if ((rc = alloc_dev(ctx->tl.esc, (size_t)esc::kTileEscCap))) return rc;
+          ctx->list_tiles_cap = n_tiles;
         }
-        if ((rc = alloc_dev(ctx->tl.esc, (size_t)esc::kTileEscCap))) return rc;
-        ctx->list_tiles_cap = n_tiles;
+        int k = 0;
+        for (esc::TileLists *L : {&ctx->sl, &ctx->tl}) {
+          if (need_ids[k++] && !L->ids) {
+            if ((rc = alloc_dev(L->ids, ctx->list_tiles_cap * esc::kTileListCap))) return rc;
+            // slots past a count are read in whole batches of 4: zeros are valid slots
+            HIP_TRY(hipMemsetAsync(L->ids, 0, ctx->list_tiles_cap * esc::kTileListCap * 4, ctx->stream));
+            ctx->lists_valid = false;
+          }
+        }
       }
       esc_context::ListKey key;
       std::memset(&key, 0, sizeof(key));
@@ -1499,7 +1511,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
         for (const esc::TileLists *L : {&p.sl, &p.tl}) {
           HIP_TRY(hipMemsetAsync(L->hdr, 0, (size_t)esc::kTileHdrInts * 4, ctx->stream));
           HIP_TRY(hipMemsetAsync(L->cnt, 0, n_tiles * 4, ctx->stream));
-          if (ctx->list_ids_stale) // slots past a count are read in whole batches: keep them valid
+          if (ctx->list_ids_stale && L->ids) // slots past a count are read in whole batches: keep them valid
             HIP_TRY(hipMemsetAsync(L->ids, 0, ctx->list_tiles_cap * esc::kTileListCap * 4, ctx->stream));
         }
         ctx->list_ids_stale = false;
@@ -1943,7 +1955,7 @@ int esc_tile_list_ids(esc_context *ctx, int32_t which, int64_t index, int32_t *i
   int64_t n = 0;
   if (which < 2) {
     const esc::TileLists &L = which ? ctx->tl : ctx->sl;
-    if (!ctx->lists_valid || !L.hdr) return 0;
+    if (!ctx->lists_valid || !L.hdr || !L.ids) return 0;
     d_ids = L.ids; d_cnt = L.cnt; cap = esc::kTileListCap;
     n = (int64_t)((ctx->list_key.W + 31) / 32) * ((ctx->list_key.n_local_rows + 3) / 4);
   } else {

@@ -266,7 +266,10 @@ struct TriGroups {
 // that does not start on a multiple of 4 rows: the tile falls back to the three-level sweep.
 // Nothing computed from a list reaches the image.
 // ---------------------------------------------------------------------------------------
-constexpr int kTileListCap = 128;   // primitives per tile (a multiple of 4)
+#ifndef ESC_TILE_CAP
+#define ESC_TILE_CAP 512
+#endif
+constexpr int kTileListCap = ESC_TILE_CAP;   // primitives per tile (a multiple of 4)
 constexpr int kTileGlobalCap = 64;  // primitives every tile tests (the camera beside them, slivers)
 constexpr int kTileMaxSpan = 8192;  // tiles one primitive may be appended to before it goes global
 constexpr int kTileEscCap = 4096;   // triangles the camera is nearly in the plane of (more: lists off this frame)

@@ -125,7 +125,7 @@ def test_list_overflow_falls_back_to_the_sweep(esc, renderer):
     """> kTileListCap spheres behind one another in one tile, and > kTileGlobalCap spheres the camera
     plane cuts: those tiles (or the whole frame) take the three-level sweep; same pixels"""
     rng = np.random.default_rng(3)
-    n = 300
+    n = 700  # > kTileListCap (512)
     line = np.stack([np.full(n, 0.02) + rng.uniform(-0.01, 0.01, n), np.full(n, 1.0),
                      -np.linspace(2.0, 60.0, n), np.linspace(0.05, 0.6, n)], axis=1)
     ang = np.linspace(0.0, 2 * np.pi, 90, endpoint=False)  # a ring in the camera plane z = 3

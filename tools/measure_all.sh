@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/final
 mkdir -p $O
 for c in c2 c3 c4 c5; do
-  timeout -k 10 300 python bench.py --config $c --steps 20 --warmup 3 > $O/bench_$c.json 2> $O/bench_$c.err || echo "bench $c failed"
+  timeout -k 10 300 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err || echo "bench $c failed"
 done
 for c in "c2 1920 1080" "c3 3840 2160" "c4 3840 2160" "c5 7680 4320"; do
   timeout -k 10 120 python tools/frame_time.py $c 2>&1 | grep -v amdgpu >> $O/frame_times.txt || true
