@@ -943,6 +943,104 @@ DEVINL void shadow_sweep_smem(const RenderParams &p, RepackLds &R, int tid, int 
   mi = __float_as_int(R.keep[7][tid]);
 }
 
+// ---- the shadow rays of light li when LISTS serve them: no re-packing, no LDS, each wave on its own.
+// shadow_sweep_smem re-packs the workgroup's undecided rays between segments of long sweeps; with the
+// light lists (rt_lists.h) a sweep is a few batches, and the parking / re-packing / barriers around
+// it cost more than the tests (c4: 0.20 of a 0.345 ms frame).  Launch-uniform condition: every
+// primitive kind of the scene is either short enough to be tested directly (< 8 triangles: the same
+// anyhit_tri call the segment loop makes) or has light lists for this light.  The calls, the
+// bookkeeping of `Any` between the kinds (triangles first; a ray a triangle stopped does not look
+// at the spheres) and the counter flags are those of shadow_sweep_smem, statement for statement.
+template <bool TGRP> DEVINL bool shadow_lists_cover(const RenderParams &p, int li) {
+  if (!p.use_filter) return false;
+  bool tri_ok = p.n_tri == 0 || p.n_tri < 8;
+  if (TGRP && p.tg.n_grp > 0)
+    tri_ok = p.lt.enabled && li < p.lt.n_listed && p.tg.n_grp * kTriGroup <= kSegGroupPairs;
+  const bool sph_ok = p.n_sph == 0 || (p.sg.n_grp > 0 && p.ll.enabled && li < p.ll.n_listed &&
+                                       p.sg.n_grp * (kSphGroup / 2) <= kSegGroupPairs);
+  return tri_ok && sph_ok;
+}
+// false: some live ray of this wave cannot be served (it starts outside the region the lists were
+// built for, or its cell overflowed) -- the caller runs shadow_sweep_smem for the workgroup with
+// the untouched `a`.  true: a.kocc / a.tocc hold what the sweep would have reported.
+template <bool TGRP>
+DEVINL bool shadow_wave_lists(const RenderParams &p, int li, f3 so, f3 sL, Any &a, int &grp_open,
+                              bool &tri_groups, bool &sph_groups, int &n_swept) {
+  const bool last_light = li == p.n_lights - 1;
+  const bool tgrp = TGRP && p.tg.n_grp > 0;
+  int n_open = 0, sw_all = 0;
+  Any out = a;
+  float tb = a.tb;
+  const bool in_box = so.x >= p.scene_lo[0] && so.x <= p.scene_hi[0] && so.y >= p.scene_lo[1] &&
+                      so.y <= p.scene_hi[1] && so.z >= p.scene_lo[2] && so.z <= p.scene_hi[2];
+  if (p.n_tri > 0) {
+    Any aa[1];
+    aa[0].tb = tb;
+    aa[0].tocc = 0.f;
+    aa[0].kocc = -1;
+    aa[0].orig = nullptr;
+    aa[0].orig_bias = aa[0].orig_add = 0;
+    if (tgrp) {
+      bool far;
+      const RayTF rt = make_ray_tri_filter(so, sL, p.shadow_center, p.shadow_rho_max, far);
+      if (!last_light) aa[0].orig = reinterpret_cast<const int32_t *>(p.tg.orig);
+      if (__builtin_amdgcn_ballot_w64(tb > 0.f && (far || !in_box)) != 0) return false;
+      const f3 Pl = ld3(p.light_points + 4 * p.lt.point[li]);
+      int n_tests = 0, sw = 0;
+      if (!anyhit_tri_light_lists(p.lt, light_list_cell(p.lt, li, Pl, so),
+                                  SmemFetch<TriPairF>{reinterpret_cast<const TriPairF *>(p.tg.sorted2_f)},
+                                  SmemFetch<DevTri>{p.tg.sorted}, 0, so, sL, rt, aa, n_tests, sw))
+        return false;
+      sw_all += sw;
+      if (tb > 0.f) n_open = (n_open + (n_tests >> 3)) | kTriListServed;
+    } else if (__builtin_amdgcn_ballot_w64(tb > 0.f) != 0) {
+      const V3<float> sov[1] = {{so.x, so.y, so.z}}, sLv[1] = {{sL.x, sL.y, sL.z}};
+      sw_all += p.n_tri;
+      anyhit_tri<float, 1>(SmemFetch<DevTri>{p.tri}, p.n_tri, 0, sov, sLv, aa);
+    }
+    if (aa[0].kocc >= 0) {
+      tb = 0.f;
+      out.tocc = aa[0].tocc;
+      out.kocc = aa[0].kocc;
+    }
+  }
+  if (p.n_sph > 0) {
+    Any aa;
+    aa.tb = tb;
+    aa.tocc = 0.f;
+    aa.kocc = -1;
+    aa.orig = nullptr;
+    aa.orig_bias = aa.orig_add = 0;
+    if (!last_light) {
+      aa.orig = reinterpret_cast<const int32_t *>(p.sg.orig);
+      aa.orig_bias = aa.orig_add = p.n_tri;
+    }
+    if (__builtin_amdgcn_ballot_w64(tb > 0.f && !in_box) != 0) return false;
+    const f3 Pl = ld3(p.light_points + 4 * p.ll.point[li]);
+    int n_tests = 0, sw = 0;
+    if (!anyhit_sph_light_lists(p.ll, light_list_cell(p.ll, li, Pl, so),
+                                SmemFetch<PairG>{reinterpret_cast<const PairG *>(p.sg.sorted2)}, p.n_tri, so, sL,
+                                aa, n_tests, sw))
+      return false;
+    sw_all += sw;
+    if (tb > 0.f) n_open = (n_open + (n_tests >> 3)) | kListServed;
+    if (aa.kocc >= 0) {
+      out.tocc = aa.tocc;
+      out.kocc = aa.kocc;
+    }
+  }
+  a.kocc = out.kocc;
+  a.tocc = out.tocc;
+  n_swept += sw_all;
+  if (last_light) { // (shadow_sweep_smem's epilogue)
+    const bool grp = p.sg.n_grp > 0;
+    if (grp || tgrp) grp_open = n_open;
+    tri_groups = tgrp;
+    sph_groups = grp;
+  }
+  return true;
+}
+
 template <int STAGE, bool TGRP = false>
 __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) k_shade(const RenderParams p) {
   typedef float V;
@@ -1394,9 +1492,27 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
         a[0].tb = t;
       }
       if (!(a[0].tb > 0.f)) a[0].tb = 0.f; // dead rays carry tb = 0
-      if (p.shadows)
-        shadow_sweep_smem<TGRP>(p, lds_rays, tid, wave, lane, li, ro, rL, a, N, r, g, b, t, mi, grp_open,
-                                tri_groups, sph_groups, n_swept);
+      if (p.shadows) {
+        bool served = false;
+        if (shadow_lists_cover<TGRP>(p, li)) { // launch-uniform
+          Any af = a[0];
+          int go = 0, sw = 0;
+          bool tg = false, sgp = false;
+          const bool ok = shadow_wave_lists<TGRP>(p, li, ro, rL, af, go, tg, sgp, sw);
+          if (!__syncthreads_or(ok ? 0 : 1)) { // every wave of the workgroup was served
+            a[0].kocc = af.kocc;
+            a[0].tocc = af.tocc;
+            grp_open = go;
+            tri_groups = tg;
+            sph_groups = sgp;
+            n_swept += sw;
+            served = true;
+          }
+        }
+        if (!served)
+          shadow_sweep_smem<TGRP>(p, lds_rays, tid, wave, lane, li, ro, rL, a, N, r, g, b, t, mi, grp_open,
+                                  tri_groups, sph_groups, n_swept);
+      }
       if (has_hit) {
         if (p.shadows) {
           n_shadow += 1u;
@@ -1750,13 +1866,17 @@ extern "C" int esc_launch_tile_lists(const esc::RenderParams *p, hipStream_t str
 // light lists of the shadow pass (rt_lists.h): hdr / cnt zeroed by the caller on this stream
 extern "C" int esc_launch_light_lists(const esc::RenderParams *p, hipStream_t stream) {
   const int n_rec = p->sg.n_grp * (esc::kSphGroup / 2);
-  if (p->ll.enabled && p->ll.n_listed > 0 && n_rec > 0)
+  if (p->ll.enabled && p->ll.n_listed > 0 && n_rec > 0) {
     hipLaunchKernelGGL(esc::k_bin_light_pairs, dim3((n_rec + 3) / 4), dim3(256), 0, stream, *p);
+    const int n_cells = p->ll.n_listed * 6 * p->ll.R * p->ll.R;
+    hipLaunchKernelGGL(esc::k_sort_light_cells<false>, dim3((n_cells + 255) / 256), dim3(256), 0, stream, *p);
+  }
   const int n_trec = p->tg.n_grp * (esc::kTriGroup / 2);
   if (p->lt.enabled && p->lt.n_listed > 0 && n_trec > 0) {
     hipLaunchKernelGGL(esc::k_bin_light_tri_pairs, dim3((n_trec + 3) / 4), dim3(256), 0, stream, *p);
     const int n_cells = p->lt.n_listed * 6 * p->lt.R * p->lt.R;
     hipLaunchKernelGGL(esc::k_bin_light_tri_escape, dim3((n_cells + 255) / 256), dim3(256), 0, stream, *p);
+    hipLaunchKernelGGL(esc::k_sort_light_cells<true>, dim3((n_cells + 255) / 256), dim3(256), 0, stream, *p);
   }
   return (int)hipGetLastError();
 }

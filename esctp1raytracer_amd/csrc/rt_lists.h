@@ -454,6 +454,63 @@ __global__ void __launch_bounds__(256) k_bin_light_pairs(const RenderParams p) {
   }
 }
 
+// The last light's sweep stops at ANY occluder (liberty 5: the order of its tests cannot be observed),
+// and a wave stops as soon as none of its rays is still looking: each cell's records are put in the
+// order of the solid angle they fill seen from P -- (r / |c - P|)^2 of the larger half -- so that a
+// ray in shadow meets its most likely occluder first.  One thread per cell, an insertion sort of at
+// most kLightListCap entries.  Nothing but the order changes (ties: the lower record first, which also
+// makes the lists independent of the order the atomics of the binning kernels happened to run in).
+template <bool TRI> __global__ void __launch_bounds__(256) k_sort_light_cells(const RenderParams p) {
+  const LightLists LL = TRI ? p.lt : p.ll;
+  const int cells_per_light = 6 * LL.R * LL.R;
+  const int cell = blockIdx.x * 256 + (int)threadIdx.x;
+  if (cell >= LL.n_listed * cells_per_light) return;
+  const int n = LL.cnt[cell];
+  if (n < 2 || n > kLightListCap) return;
+  const int li = cell / cells_per_light;
+  const float P[3] = {p.light_points[4 * LL.point[li]], p.light_points[4 * LL.point[li] + 1],
+                      p.light_points[4 * LL.point[li] + 2]};
+  auto key_of = [&](int j) -> float {
+    float best = 0.f;
+    for (int h = 0; h < 2; ++h) {
+      float r2, d2;
+      if (TRI) {
+        const DevTri T = p.tg.sorted[2 * j + h];
+        const float c[3] = {T.v0[0] + (T.e1[0] + T.e2[0]) / 3.f - P[0], T.v0[1] + (T.e1[1] + T.e2[1]) / 3.f - P[1],
+                            T.v0[2] + (T.e1[2] + T.e2[2]) / 3.f - P[2]};
+        const float x[3] = {T.e1[1] * T.e2[2] - T.e1[2] * T.e2[1], T.e1[2] * T.e2[0] - T.e1[0] * T.e2[2],
+                            T.e1[0] * T.e2[1] - T.e1[1] * T.e2[0]};
+        r2 = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]); // twice the area
+        d2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+      } else {
+        const DevSphPair S = p.sg.sorted2[j];
+        const float c[3] = {S.cx[h] - P[0], S.cy[h] - P[1], S.cz[h] - P[2]};
+        r2 = S.r2[h]; // a pad half: -inf
+        d2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+      }
+      const float k = r2 / fmaxf(d2, 1e-30f);
+      if (k > best) best = k; // (NaN: not larger)
+    }
+    return best;
+  };
+  int32_t *ids = LL.ids + (size_t)cell * kLightListCap;
+  int32_t v[kLightListCap];
+  float key[kLightListCap];
+  for (int i = 0; i < n; ++i) {
+    const int32_t id = ids[i];
+    const float k = key_of(id);
+    int q = i;
+    while (q > 0 && (key[q - 1] < k || (key[q - 1] == k && v[q - 1] > id))) {
+      key[q] = key[q - 1];
+      v[q] = v[q - 1];
+      --q;
+    }
+    key[q] = k;
+    v[q] = id;
+  }
+  for (int i = 0; i < n; ++i) ids[i] = v[i];
+}
+
 // the cell (over all listed lights and faces) of the shadow ray that starts at `o` towards the
 // sample point P of listed light li
 DEVINL int light_list_cell(const LightLists &LL, int li, f3 P, f3 o) {
