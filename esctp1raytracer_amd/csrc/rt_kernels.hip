@@ -1197,8 +1197,25 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
         a[0].tocc = s.thit;
         cnt_lane = (uint32_t)n_tests;
       } else if constexpr (STAGE == STAGE_SMEM) {
-        shadow_sweep_smem<TGRP>(p, lds_rays, tid, wave, lane, li, ro, rL, a, N, r, g, b, t, mi, grp_open,
-                                tri_groups, sph_groups, n_swept);
+        bool served = false;
+        if (shadow_lists_cover<TGRP>(p, li)) { // launch-uniform (see k_frame)
+          Any af = a[0];
+          int go = 0, sw = 0;
+          bool tg = false, sgp = false;
+          const bool ok = shadow_wave_lists<TGRP>(p, li, ro, rL, af, go, tg, sgp, sw);
+          if (!__syncthreads_or(ok ? 0 : 1)) {
+            a[0].kocc = af.kocc;
+            a[0].tocc = af.tocc;
+            grp_open = go;
+            tri_groups = tg;
+            sph_groups = sgp;
+            n_swept += sw;
+            served = true;
+          }
+        }
+        if (!served)
+          shadow_sweep_smem<TGRP>(p, lds_rays, tid, wave, lane, li, ro, rL, a, N, r, g, b, t, mi, grp_open,
+                                  tri_groups, sph_groups, n_swept);
       } else {
         const V3<V> ov[1] = {{ro.x, ro.y, ro.z}}, Lv[1] = {{rL.x, rL.y, rL.z}};
         constexpr int CT = kLdsChunkBytes / (int)sizeof(DevTri);
