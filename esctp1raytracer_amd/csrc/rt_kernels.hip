@@ -1874,8 +1874,7 @@ extern "C" int esc_launch_tile_lists(const esc::RenderParams *p, hipStream_t str
     hipLaunchKernelGGL(esc::k_bin_spheres, dim3(p->sg.n_grp * esc::kSphGroup / 4), dim3(256), 0, stream, *p);
   if (p->tl.enabled && p->tg.n_grp > 0) {
     hipLaunchKernelGGL(esc::k_bin_triangles, dim3(p->tg.n_grp * esc::kTriGroup / 4), dim3(256), 0, stream, *p);
-    const long long n_thr = (long long)esc::kTileEscCap * p->tl.tile_rows; // (entries counted on the device)
-    hipLaunchKernelGGL(esc::k_bin_tri_escape, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream, *p);
+    hipLaunchKernelGGL(esc::k_bin_tri_escape, dim3((unsigned)p->tl.tile_rows), dim3(256), 0, stream, *p);
   }
   return (int)hipGetLastError();
 }

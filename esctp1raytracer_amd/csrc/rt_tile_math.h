@@ -151,7 +151,7 @@ HDINL int sphere_pixel_rect(const CamD &cam, int W, int H, const double c[3], do
 // The image-plane rectangle [s0, s1] x [t0, t1] that holds the (s, t) of every ray the reference
 // computes for the pixels [32 tx, 32 tx + 32) x [h, h + 4) (grown like the sphere rectangles), and
 // pmax >= |A + s H + t V| over it (|p| is convex: the largest value is at a corner).
-HDINL void tile_st_rect(const RenderParams &p, const CamD &cam, int tx, int h, double st[4], double &pmax) {
+HDINL void tile_st(const RenderParams &p, const CamD &cam, int tx, int h, double st[4]) {
   const double W1 = (double)(p.W - 1), H1 = (double)(p.H - 1);
   const double pw = 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1;
   const double ph = 1.0 + (cam.nb2 + cam.nb3) * cam.eps_p * 1.01 * H1;
@@ -159,7 +159,9 @@ HDINL void tile_st_rect(const RenderParams &p, const CamD &cam, int tx, int h, d
   st[1] = (32.0 * tx + 31.0 + pw) / W1;
   st[2] = ((double)h - ph) / H1;
   st[3] = ((double)h + 3.0 + ph) / H1;
-  pmax = 0.0;
+}
+HDINL double tile_pmax(const RenderParams &p, const CamD &cam, const double st[4]) {
+  double pmax = 0.0;
   for (int k = 0; k < 4; ++k) {
     double q[3];
     for (int j = 0; j < 3; ++j)
@@ -167,7 +169,11 @@ HDINL void tile_st_rect(const RenderParams &p, const CamD &cam, int tx, int h, d
              ((k & 2) ? st[3] : st[2]) * (double)p.vertical[j];
     pmax = fmax(pmax, sqrt(dot3(q, q)));
   }
-  pmax *= 1.0 + 1e-9;
+  return pmax * (1.0 + 1e-9);
+}
+HDINL void tile_st_rect(const RenderParams &p, const CamD &cam, int tx, int h, double st[4], double &pmax) {
+  tile_st(p, cam, tx, h, st);
+  pmax = tile_pmax(p, cam, st);
 }
 // can a ray of that rectangle have |d . n| <= kp, d = p / |p|?  p . n = fA + s fH + t fV is affine in
 // (s, t), so its range over the rectangle is spanned by the corners
@@ -182,20 +188,17 @@ HDINL bool tile_band_hit(const double st[4], double pmax, double fA, double fH, 
 // can fall into, p . n = fA + s fH + t fV (affine in the image-plane coordinates): over the row's t range
 // the band is an interval of s.  Returns 1 (tx0 <= tx1: those tiles; tx0 > tx1: none) or 0 (nothing can
 // be said: the caller switches the lists off).
-HDINL int band_row_tiles(const RenderParams &p, const CamD &cam, int h, int tiles_x, double fA, double fH,
-                         double fV, double kp, int &tx0, int &tx1) {
-  double st[4], pmax_l, pmax_r;
-  tile_st_rect(p, cam, 0, h, st, pmax_l);
-  const double t0 = st[2], t1 = st[3];
-  tile_st_rect(p, cam, tiles_x - 1, h, st, pmax_r);
-  const double pmax = fmax(pmax_l, pmax_r); // |p| is convex: over the row strip it peaks at an end
+// (pmax_row: the larger of the two end tiles' pmax -- |p| is convex, over the row strip it peaks at an
+// end; t0, t1: the row's t range, tile_st's st[2], st[3])
+HDINL int band_row_tiles_with(const RenderParams &p, const CamD &cam, int tiles_x, double pmax, double t0,
+                              double t1, double fA, double fH, double fV, double kp, int &tx0, int &tx1) {
   const double w = kp * pmax + 1e-12 * (fabs(fA) + fabs(fH) + fabs(fV));
   const double g_lo = fA + fmin(t0 * fV, t1 * fV), g_hi = fA + fmax(t0 * fV, t1 * fV);
   if (!(pmax == pmax) || !(pmax < 1e150) || !(w == w) || !(g_lo == g_lo) || !(g_hi == g_hi)) return 0;
   // some t in the row with |g(t) + s fH| <= w  <=>  s fH in [-w - g_hi, w - g_lo]
   const double lo = -w - g_hi, hi = w - g_lo;
   const double W1 = (double)(p.W - 1);
-  const double pw = 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1; // (tile_st_rect's growth)
+  const double pw = 1.0 + (cam.nb1 + cam.nb3) * cam.eps_p * 1.01 * W1; // (tile_st's growth)
   tx0 = 0;
   tx1 = tiles_x - 1;
   if (fabs(fH) * (W1 + 2.0 * pw) > 1e-280) {
@@ -209,6 +212,14 @@ HDINL int band_row_tiles(const RenderParams &p, const CamD &cam, int h, int tile
     tx1 = 0;
   }
   return 1;
+}
+HDINL int band_row_tiles(const RenderParams &p, const CamD &cam, int h, int tiles_x, double fA, double fH,
+                         double fV, double kp, int &tx0, int &tx1) {
+  double st[4], pmax_l, pmax_r;
+  tile_st_rect(p, cam, 0, h, st, pmax_l);
+  const double t0 = st[2], t1 = st[3];
+  tile_st_rect(p, cam, tiles_x - 1, h, st, pmax_r);
+  return band_row_tiles_with(p, cam, tiles_x, fmax(pmax_l, pmax_r), t0, t1, fA, fH, fV, kp, tx0, tx1);
 }
 
 } // namespace esc
