@@ -617,13 +617,13 @@ def main():
                       "BASELINE's brute-force intersect",
             "culled": ("culled sweep of the primitive table (not brute force): per camera, every "
                        "32x4-pixel tile lists the primitives its primary rays can touch; per one-point "
-                       "light, every direction cell lists the sphere pairs a shadow ray can reach "
-                       "(projected bounds grown by the reference's rounding reach, csrc/rt_lists.h); "
-                       "listed primitives go through the proven filters and the reference arithmetic; "
-                       "what the lists cannot serve -- overflowing tiles / cells, triangle shadow "
-                       "rays, multi-point lights -- sweeps 3 levels of spatial groups (8 / 64-128 / "
-                       "512-1,024 primitives: DESIGN.md 3.6-3.7); tables under 64 primitives are "
-                       "swept linearly"),
+                       "light, every direction cell of a cube map around it lists the sphere / triangle "
+                       "pair records a shadow ray can reach (projected bounds grown by the reference's "
+                       "rounding reach, csrc/rt_lists.h); listed primitives go through the proven "
+                       "filters and the reference arithmetic; what the lists cannot serve -- "
+                       "overflowing tiles / cells, multi-point lights, rays that start outside the "
+                       "scene box -- sweeps 3 levels of spatial groups (8 / 64-128 / 512-1,024 "
+                       "primitives: DESIGN.md 3.6-3.7); tables under 64 primitives are swept linearly"),
         }["bvh" if a.stage == "bvh" else a.path]
         out = {
             "metric": "Mrays/sec + frame ms, 3840x2160 / 10k spheres, at 1/2/4/8 MI355X",

@@ -33,9 +33,15 @@ def condense(src, dst):
     for f in glob.glob(os.path.join(src, "pmc_*", "**", "pmc_counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
-        for r in csv.DictReader(open(f)):
+        rows = [r for r in csv.DictReader(open(f)) if "esc::" in r["Kernel_Name"]]
+        # bench.py also launches the frame kernels on a few sample rows (parity spot-check) and on rank
+        # shares: only launches with the kernel's LARGEST grid are whole frames
+        biggest = collections.defaultdict(int)
+        for r in rows:
+            biggest[r["Kernel_Name"]] = max(biggest[r["Kernel_Name"]], int(r.get("Grid_Size", 0) or 0))
+        for r in rows:
             k = r["Kernel_Name"]
-            if "esc::" not in k:
+            if int(r.get("Grid_Size", 0) or 0) != biggest[k]:
                 continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = {x: r[x] for x in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
@@ -64,10 +70,13 @@ def kernel_class(name):
     return None
 
 
-def per_frame(out):
-    """per-FRAME sums of every counter per kernel class; frames = launches of the per-frame kernel
-    (k_primary or k_frame: exactly one launch per frame)"""
-    anchor = [k for k in out if kernel_class(k) in ("k_primary", "k_frame")]
+def per_frame(out, path):
+    """per-FRAME sums of every counter per kernel class of the path's frame: culled = k_frame alone
+    (the k_primary / k_shade launches of that run are bench.py's two-kernel split and are kept out),
+    linear = k_primary + the queue-form shading kernels; frames = whole-frame launches of the anchor"""
+    want = ("k_frame",) if path == "culled" else ("k_primary", "k_shade")
+    out = {k: v for k, v in out.items() if kernel_class(k) in want}
+    anchor = [k for k in out if kernel_class(k) == want[0]]
     if not anchor:
         return {}, {}
     frames = {c: sum(out[k][c]["launches"] for k in anchor if c in out[k])
@@ -101,7 +110,7 @@ else:
         if not os.path.isdir(os.path.join(src, path)):
             continue
         out, _ = condense(os.path.join(src, path), os.path.join(dst, path))
-        cls, frames = per_frame(out)
+        cls, frames = per_frame(out, path)
         ent = {"kernels": cls}
         if frames.get("FETCH_SIZE") and frames.get("WRITE_SIZE"):
             # rocprofv3 reports KB; FETCH_SIZE counts 64-byte requests of 128-byte lines on gfx950 ->
