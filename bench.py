@@ -124,9 +124,10 @@ def parse():
     ap.add_argument("--no-accel", action="store_true",
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
     ap.add_argument("--profile-run", action="store_true",
-                    help="render default-path frames only (no index-order frame for the reference's "
-                         "test count): what tools/profile.sh wants under rocprofv3, so that every "
-                         "launch in the trace belongs to a timed frame's path")
+                    help="render whole frames of the timed path only (no index-order frame for the "
+                         "reference's test count, no rank-share launches): what tools/profile.sh wants "
+                         "under rocprofv3, so that every launch in the trace belongs to a timed frame's "
+                         "path and the trace's average duration is a frame's")
     ap.add_argument("--pipelined", action="store_true",
                     help="N=1: also time the same K frames with two in flight on two streams "
                          "(information only; off by default so that a rocprofv3 trace of the "
@@ -522,7 +523,9 @@ def main():
                         "esc_frame_launch (one hipGraphLaunch); through the Python binding",
                 "timed_steps_use": "recorded" if a.graph else "plain"}
         share = torch.zeros(multigpu.max_local_rows(H, 8, S) * W * 3, dtype=ch_dtype, device=dev)
-        for label, fs, stride, out in (("whole_frame", 0, 1, local[0]), ("rank_0_of_8", 0, 8, share)):
+        # (--profile-run: whole frames only, so that the trace's average k_frame duration is a frame's)
+        for label, fs, stride, out in ((("whole_frame", 0, 1, local[0]),) if a.profile_run else
+                                       (("whole_frame", 0, 1, local[0]), ("rank_0_of_8", 0, 8, share))):
             kw = dict(out_f32=None if use_u8 else out, out_u8=out if use_u8 else None, strip_rows=S,
                       shadows=shadows, stage=stage, flags=path_flags)
             n_rep = max(a.steps, 20)
