@@ -696,6 +696,11 @@ def main():
                                    "SQ_WAVE_CYCLES; instructions are wave instructions"}
             for pname, pp in prof["paths"].items():
                 valu[pname] = {k: counter_view(v) for k, v in pp.get("kernels", {}).items()}
+                # per pixel of the frame: wave instructions x 64 lanes / pixels, all kernels of the path
+                tot_v = sum(v.get("SQ_INSTS_VALU", 0.0) for v in pp.get("kernels", {}).values())
+                tot_s = sum(v.get("SQ_INSTS_SALU", 0.0) for v in pp.get("kernels", {}).values())
+                valu[pname]["valu_lane_insts_per_pixel"] = tot_v * 64.0 / (W * H)
+                valu[pname]["salu_insts_per_64_pixels"] = tot_s * 64.0 / (W * H)
             out["valu"] = valu
         if linear is not None:
             lin_bytes = alg_bytes
