@@ -280,10 +280,10 @@ def oracle_camera(lookfrom, lookat, W, H, vup=(0, 1, 0), vfov=60.0):
 
 def oracle_render(d, lookfrom, lookat, W, H, *, shadows=True, face_mode=ORC_FACE_FIXED,
                   fixed_face=0, seed=0, quirks=ORC_QUIRK_ALL, rows=None, threads=1,
-                  return_counters=False):
+                  return_counters=False, vfov=60.0):
     """fp32 (H, W, 3) image, h = 0 bottom row; rows outside `rows` stay zero."""
     osc = d if isinstance(d, OracleScene) else OracleScene(d)
-    cam = oracle_camera(lookfrom, lookat, W, H)
+    cam = oracle_camera(lookfrom, lookat, W, H, vfov=vfov)
     o = orc_options(1 if shadows else 0, face_mode, fixed_face, seed, quirks)
     img = np.zeros((H, W, 3), np.float32)
     cnt = orc_counters()
