@@ -99,8 +99,8 @@ def counter_view(kern):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="c4", help="c2|c3|c4|c5 (BASELINE.json configs 2-5)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -528,7 +528,7 @@ def main():
                                        (("whole_frame", 0, 1, local[0]), ("rank_0_of_8", 0, 8, share))):
             kw = dict(out_f32=None if use_u8 else out, out_u8=out if use_u8 else None, strip_rows=S,
                       shadows=shadows, stage=stage, flags=path_flags)
-            n_rep = max(a.steps, 20)
+            n_rep = min(max(a.steps, 20), 100)  # (well below the depth at which the queue blocks the host)
             with torch.cuda.stream(st):
                 rec = r.record_strips(cam, W, H, fs, stride, **kw)
                 r.synchronize()
