@@ -261,14 +261,18 @@ enum {
    * csrc/rt_lists.h), and a wavefront tests its tile's primitives directly.  Same filters and
    * reference arithmetic behind the lists, same image.  This flag (or $ESC_LISTS=0) keeps the
    * three-level sweep of round 2 for every tile -- the A/B switch and a cross-check in tests; tiles
-   * whose lists overflow take that sweep anyway. */
+   * whose lists overflow (more than 512 primitives) take that sweep anyway.  The lists cost 2 KB of
+   * device memory per tile and primitive kind the scene has: 133 MB for a 4K frame, 531 MB at 8K. */
   ESC_RENDER_NO_TILE_LISTS = 32,
   /* The same from the light's end: a light that offers one sample point this frame (a one-face
-   * light, or ESC_FACE_FIXED) has all its shadow rays on lines through that point, so the spheres a
-   * ray can reach are listed per direction cell of a cube map around the point, once per scene
-   * (csrc/rt_lists.h "Light lists"); a wavefront looks its rays' cells up and tests those lists with
-   * the reference arithmetic.  This flag (or $ESC_LLISTS=0) keeps the three-level group sweep for
-   * every shadow ray; rays the lists cannot serve take it anyway. */
+   * light, or ESC_FACE_FIXED; the first 4 such lights) has all its shadow rays on lines through that
+   * point, so the spheres / triangles a ray can reach are listed (as pair records) per direction cell
+   * of a cube map around the point, once per scene and sample point (csrc/rt_lists.h "Light lists",
+   * 25 MB per light and kind); a wavefront looks its rays' cells up and tests those lists -- inside
+   * the wavefront, without the workgroup-wide re-packing of the sweeps, when every primitive kind of
+   * the scene is covered.  This flag (or $ESC_LLISTS=0) keeps the three-level group sweep for every
+   * shadow ray; rays the lists cannot serve (an overflowing cell, an origin outside the scene box)
+   * take it anyway. */
   ESC_RENDER_NO_LIGHT_LISTS = 64,
   /* The default frame of the scalar-cache staging is ONE kernel (k_frame: closest hit and shading
    * of a 64 x 8 tile; no hit planes through HBM).  This flag (or $ESC_FRAME=2) keeps the two kernels
