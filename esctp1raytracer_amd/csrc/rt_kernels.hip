@@ -968,6 +968,15 @@ DEVINL bool shadow_wave_lists(const RenderParams &p, int li, f3 so, f3 sL, Any &
                               bool &tri_groups, bool &sph_groups, int &n_swept) {
   const bool last_light = li == p.n_lights - 1;
   const bool tgrp = TGRP && p.tg.n_grp > 0;
+  if (__builtin_amdgcn_ballot_w64(a.tb > 0.f) == 0) { // no ray in this wave (sky, lights behind): nothing
+    if (last_light) {                                  // to sweep; the flags of a sweep that tested nothing
+      const bool grp = p.sg.n_grp > 0;
+      if (grp || tgrp) grp_open = 0;
+      tri_groups = tgrp;
+      sph_groups = grp;
+    }
+    return true;
+  }
   int n_open = 0, sw_all = 0;
   Any out = a;
   float tb = a.tb;
