@@ -627,7 +627,9 @@ def main():
                        "overflowing tiles / cells, multi-point lights, rays that start outside the "
                        "scene box -- sweeps 3 levels of spatial groups (8 / 64-128 / 512-1,024 "
                        "primitives: DESIGN.md 3.6-3.7); tables under 64 primitives are swept linearly"),
-        }["bvh" if a.stage == "bvh" else a.path]
+            "lds": "ESC_STAGE_LDS: primitives staged through LDS chunks, the reference arithmetic for every "
+                   "(ray, primitive) pair -- no filters, no groups, no lists (the A/B path)",
+        }[a.stage if a.stage in ("bvh", "lds") else a.path]
         out = {
             "metric": "Mrays/sec + frame ms, 3840x2160 / 10k spheres, at 1/2/4/8 MI355X",
             "value": rays / elapsed / 1e6,
@@ -647,7 +649,7 @@ def main():
                             f"{info['n_lights']} light, 1 primary ray/pixel + "
                             f"{'1 shadow ray per hit pixel' if shadows else 'no shadow rays'}; "
                             f"{algorithm}",
-                "path": "bvh" if a.stage == "bvh" else a.path,
+                "path": a.stage if a.stage in ("bvh", "lds") else a.path,
                 "scene": "esc_scene_synthetic (SURVEY.md 8(d)): splitmix64 seeds 0xC2..0xC4",
                 "partition": f"{S}-row strips round-robin over {world} rank(s)",
                 "gather": ("none (1 GPU)" if world == 1 else
@@ -727,7 +729,7 @@ def main():
             # like for like: the CPU baseline sweeps every pair linearly, as `linear` does
             out["gpu_vs_cpu"] = {
                 "linear_over_cpu": (linear["value"] / cb["value"]) if linear else None,
-                ("bvh" if a.stage == "bvh" else a.path) + "_over_cpu": out["value"] / cb["value"]}
+                (a.stage if a.stage in ("bvh", "lds") else a.path) + "_over_cpu": out["value"] / cb["value"]}
             out["parity_sample_rows_bit_exact"] = same
         if world == 1 and a.stage != "bvh" and not a.no_accel and not use_u8:
             out["accel"] = accel_leg(esc, r, st, cam, eye, look, W, H, shadows, a.steps, a.warmup,
