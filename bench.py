@@ -123,6 +123,12 @@ def parse():
                          "the GPU back to back (`host` reports both)")
     ap.add_argument("--no-accel", action="store_true",
                     help="skip the extra ESC_STAGE_BVH leg reported under \"accel\" (N=1 only)")
+    ap.add_argument("--count-every-frame", action="store_true",
+                    help="keep the library's ray counters on in the timed frames.  By default the timed "
+                         "frames run with ESC_RENDER_NO_COUNTERS and the rays are counted on ONE identical "
+                         "frame before the timed region: the counters are instrumentation the reference does "
+                         "not have (two barriers + atomics per workgroup: 9 %% of a c4 frame), and every "
+                         "frame of a fixed scene, camera and option set counts the same rays")
     ap.add_argument("--profile-run", action="store_true",
                     help="render whole frames of the timed path only (no index-order frame for the "
                          "reference's test count, no rank-share launches): what tools/profile.sh wants "
@@ -167,7 +173,8 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def accel_leg(esc, r, st, cam, eye, look_at, W, H, shadows, steps, warmup, brute_frame, alg_bytes):
+def accel_leg(esc, r, st, cam, eye, look_at, W, H, shadows, steps, warmup, brute_frame, alg_bytes,
+              count_every_frame=False):
     """The same frame through ESC_STAGE_BVH (opt-in like the reference's --bvh):
     tree build timed apart from the render (as main.cpp:569-579 does), K frames between HIP
     events on the render stream, and EVERY fp32 value compared with the brute-force frame."""
@@ -176,10 +183,19 @@ def accel_leg(esc, r, st, cam, eye, look_at, W, H, shadows, steps, warmup, brute
     ev = []
     r.synchronize()
     t0 = 0.0
+    tree_flags = esc.ESC_RENDER_BVH_HEURISTIC_PADS
+    timed_flags = tree_flags | (0 if count_every_frame else esc.ESC_RENDER_NO_COUNTERS)
+    frame_cnt = None
     for i in range(warmup + steps):
         if i == warmup:
             r.synchronize()
             r.reset_counters()
+            if not count_every_frame:  # one counted frame, then K timed ones without the counters
+                with torch.cuda.stream(st):
+                    r.render_rows(cam, W, H, 0, H, out_f32=buf, shadows=shadows, stage=esc.ESC_STAGE_BVH,
+                                  flags=tree_flags)
+                r.synchronize()
+                frame_cnt = r.counters()
             r.synchronize()
             t0 = time.perf_counter()
         with torch.cuda.stream(st):
@@ -187,13 +203,13 @@ def accel_leg(esc, r, st, cam, eye, look_at, W, H, shadows, steps, warmup, brute
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(st)
             r.render_rows(cam, W, H, 0, H, out_f32=buf, shadows=shadows, stage=esc.ESC_STAGE_BVH,
-                          flags=esc.ESC_RENDER_BVH_HEURISTIC_PADS)
+                          flags=timed_flags)
             e1.record(st)
         if i >= warmup:
             ev.append((e0, e1))
     st.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3 / steps
-    cnt = r.counters()
+    cnt = r.counters() if frame_cnt is None else {k: v * steps for k, v in frame_cnt.items()}
     ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     differing = int((buf.view(torch.int32) != brute_frame[:H * W * 3].view(torch.int32)).sum().item())
     # a camera that moves every frame: the per-camera constants (k_prepare_*) and the screen bins
@@ -210,7 +226,7 @@ def accel_leg(esc, r, st, cam, eye, look_at, W, H, shadows, steps, warmup, brute
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(st)
             r.render_rows(c, W, H, 0, H, out_f32=buf, shadows=shadows, stage=esc.ESC_STAGE_BVH,
-                          flags=esc.ESC_RENDER_BVH_HEURISTIC_PADS)
+                          flags=timed_flags)
             e1.record(st)
         mv.append((e0, e1))
     st.synchronize()
@@ -315,6 +331,8 @@ def main():
     stage = {"auto": esc.ESC_STAGE_AUTO, "smem": esc.ESC_STAGE_SMEM, "lds": esc.ESC_STAGE_LDS,
              "bvh": esc.ESC_STAGE_BVH}[a.stage]
     path_flags = esc.ESC_RENDER_INDEX_ORDER if a.path == "linear" else 0
+    # the TIMED frames: the same, without the ray counters (see --count-every-frame)
+    timed_flags = path_flags | (0 if a.count_every_frame else esc.ESC_RENDER_NO_COUNTERS)
 
     st = torch.cuda.Stream(device=dev)
     r = esc.Renderer(local_rank, stream=st)
@@ -361,7 +379,7 @@ def main():
                 recorded[b] = renderers[b % len(renderers)].record_strips(
                     cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
                     out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows, stage=stage,
-                    flags=path_flags)
+                    flags=timed_flags)
         for rr in renderers:
             rr.synchronize()
 
@@ -392,7 +410,7 @@ def main():
         else:
             rr.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[b],
                              out_u8=local[b] if use_u8 else None, strip_rows=S, shadows=shadows,
-                             stage=stage, flags=path_flags)
+                             stage=stage, flags=timed_flags)
         e1.record(ss)
         if timed:
             events.append((e0, e1))
@@ -424,16 +442,30 @@ def main():
     fence()
     for rr in renderers:
         rr.reset_counters()
+    frame_cnt = None
+    if not a.count_every_frame:
+        # the rays of ONE frame of this rank, counted outside the timed region on the frame the timed
+        # steps render (same scene, camera, strips and options; only the counters differ)
+        with torch.cuda.stream(st):
+            r.render_strips(cam, W, H, rank, world, out_f32=None if use_u8 else local[0],
+                            out_u8=local[0] if use_u8 else None, strip_rows=S, shadows=shadows,
+                            stage=stage, flags=path_flags)
+        r.synchronize()
+        frame_cnt = r.counters()
+        r.reset_counters()
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, True)
     fence()
     elapsed = time.perf_counter() - t0
-    cnt = renderers[0].counters()  # rays of exactly the K timed frames
-    for rr in renderers[1:]:
-        for k, v in rr.counters().items():
-            cnt[k] += v
+    if frame_cnt is not None:
+        cnt = {k: v * a.steps for k, v in frame_cnt.items()}  # K identical frames
+    else:
+        cnt = renderers[0].counters()  # rays of exactly the K timed frames
+        for rr in renderers[1:]:
+            for k, v in rr.counters().items():
+                cnt[k] += v
 
     # per-kernel durations (HIP events recorded by the library between the frame's kernels):
     # a few extra frames outside the timed region, one at a time
@@ -527,7 +559,7 @@ def main():
         for label, fs, stride, out in ((("whole_frame", 0, 1, local[0]),) if a.profile_run else
                                        (("whole_frame", 0, 1, local[0]), ("rank_0_of_8", 0, 8, share))):
             kw = dict(out_f32=None if use_u8 else out, out_u8=out if use_u8 else None, strip_rows=S,
-                      shadows=shadows, stage=stage, flags=path_flags)
+                      shadows=shadows, stage=stage, flags=timed_flags)
             n_rep = min(max(a.steps, 20), 100)  # (well below the depth at which the queue blocks the host)
             with torch.cuda.stream(st):
                 rec = r.record_strips(cam, W, H, fs, stride, **kw)
@@ -658,6 +690,11 @@ def main():
                            f"on a second stream overlapping the next frame's render; consecutive "
                            f"frames alternate between two render streams"),
                 "stage": a.stage,
+                "rays_counted": ("in every timed frame (--count-every-frame)" if a.count_every_frame else
+                                 "on ONE frame before the timed region, x steps: the library's ray counters "
+                                 "are instrumentation the reference does not have (two barriers + atomics "
+                                 "per workgroup, 9 % of a c4 frame); the timed frames render the same "
+                                 "scene, camera, strips and options with ESC_RENDER_NO_COUNTERS"),
                 "rays_per_frame": rays / a.steps,
                 "primary_rays_per_frame": primary / a.steps,
                 "shadow_rays_per_frame": shadow / a.steps,
@@ -733,7 +770,7 @@ def main():
             out["parity_sample_rows_bit_exact"] = same
         if world == 1 and a.stage != "bvh" and not a.no_accel and not use_u8:
             out["accel"] = accel_leg(esc, r, st, cam, eye, look, W, H, shadows, a.steps, a.warmup,
-                                     local[0], alg_bytes)
+                                     local[0], alg_bytes, a.count_every_frame)
         if world > 1 and a.verify_rows > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import numpy as np

@@ -14,14 +14,14 @@ import numpy as np
 from . import _capi
 from ._capi import (ESC_FACE_FIXED, ESC_FACE_HASH, ESC_STAGE_AUTO, ESC_STAGE_BVH, ESC_STAGE_LDS,
                     ESC_RENDER_EXACT_ONLY, ESC_RENDER_INDEX_ORDER, ESC_RENDER_SHADE_FUSED,
-                    ESC_RENDER_SHADE_QUEUE, ESC_RENDER_TIME_KERNELS, ESC_RENDER_NO_TILE_LISTS, ESC_RENDER_NO_LIGHT_LISTS, ESC_RENDER_TWO_KERNELS, ESC_RENDER_BVH_HEURISTIC_PADS,
+                    ESC_RENDER_SHADE_QUEUE, ESC_RENDER_TIME_KERNELS, ESC_RENDER_NO_TILE_LISTS, ESC_RENDER_NO_LIGHT_LISTS, ESC_RENDER_TWO_KERNELS, ESC_RENDER_BVH_HEURISTIC_PADS, ESC_RENDER_NO_COUNTERS,
                     ESC_STAGE_SMEM, EscError,
                     check)
 
 __all__ = ["Scene", "Camera", "Renderer", "RecordedFrame", "FlatScene", "MultiRenderer", "render_multi", "render_multi_rccl", "rccl_available", "strip_local_rows", "trace", "write_ppm", "quantise", "synthetic_view",
            "EscError", "ESC_FACE_FIXED", "ESC_FACE_HASH", "ESC_STAGE_AUTO", "ESC_STAGE_SMEM",
            "ESC_STAGE_LDS", "ESC_STAGE_BVH", "ESC_RENDER_EXACT_ONLY", "ESC_RENDER_TIME_KERNELS", "ESC_RENDER_INDEX_ORDER", "ESC_RENDER_SHADE_QUEUE",
-           "ESC_RENDER_SHADE_FUSED", "ESC_RENDER_NO_TILE_LISTS", "ESC_RENDER_NO_LIGHT_LISTS", "ESC_RENDER_TWO_KERNELS", "ESC_RENDER_BVH_HEURISTIC_PADS", "version"]
+           "ESC_RENDER_SHADE_FUSED", "ESC_RENDER_NO_TILE_LISTS", "ESC_RENDER_NO_LIGHT_LISTS", "ESC_RENDER_TWO_KERNELS", "ESC_RENDER_BVH_HEURISTIC_PADS", "ESC_RENDER_NO_COUNTERS", "version"]
 
 
 def _f32(a, shape=None):

@@ -36,6 +36,7 @@ ESC_RENDER_NO_TILE_LISTS = 32
 ESC_RENDER_NO_LIGHT_LISTS = 64
 ESC_RENDER_TWO_KERNELS = 128
 ESC_RENDER_BVH_HEURISTIC_PADS = 256
+ESC_RENDER_NO_COUNTERS = 512
 
 
 class EscError(RuntimeError):

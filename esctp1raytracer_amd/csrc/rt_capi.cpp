@@ -1418,7 +1418,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.seed = opts->seed;
   p.out_f32 = d_rgb_f32;
   p.out_u8 = d_rgb_u8;
-  p.counters = ctx->d_counters;
+  p.counters = (opts->flags & ESC_RENDER_NO_COUNTERS) ? nullptr : ctx->d_counters;
   {
     const size_t need = (size_t)n_local_rows * W;
     if (ctx->hits_cap < need) {

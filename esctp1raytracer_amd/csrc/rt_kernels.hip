@@ -1540,7 +1540,7 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
                                   tri_groups, sph_groups, n_swept);
       }
       if (has_hit) {
-        if (p.shadows) {
+        if (p.shadows && p.counters) { // (instrumentation: ESC_RENDER_NO_COUNTERS skips it)
           n_shadow += 1u;
           const int k = a[0].kocc; // (the counter rules of k_shade)
           const bool by_tri = k >= 0 && k < p.n_tri;

@@ -287,7 +287,13 @@ enum {
    * scale) -- faster on large meshes, every test and hunt so far bit-identical, but for rays within
    * ~1e-3 rad of a triangle's plane whose rounding-noise hit lies further than the pad outside the
    * triangle it may cull a hit the reference reports. */
-  ESC_RENDER_BVH_HEURISTIC_PADS = 256
+  ESC_RENDER_BVH_HEURISTIC_PADS = 256,
+  /* The ray counters (esc_counters: instrumentation the reference does not have) are not updated by
+   * this call.  Counting costs two workgroup barriers, a handful of LDS and global atomics per
+   * workgroup and a wave reduction per light and pixel: 9 % of a c4 frame.  Every frame of a fixed
+   * scene, camera and option set counts the same rays, so a caller that wants both (bench.py) counts
+   * one frame and times the others. */
+  ESC_RENDER_NO_COUNTERS = 512
 };
 
 typedef struct {

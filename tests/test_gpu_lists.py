@@ -425,3 +425,20 @@ def test_random_scenes_lists_equal_sweep_and_oracle(esc, renderer):
         lit += 1 if a.any() else 0
         listed += 1 if any(s is not None and s["off"] == 0 for s in st) else 0
     assert lit > 30 and listed > 50, (lit, listed)
+
+
+def test_no_counters_flag_renders_the_same_frame_and_counts_nothing(esc, renderer):
+    """ESC_RENDER_NO_COUNTERS: the instrumentation is off for that call -- same image bit for bit,
+    the counters stay where they were (bench.py times such frames and counts the rays on one other)"""
+    sc, d = synthetic_dict(esc, "c3", 600)
+    renderer.upload(sc)
+    eye, look = esc.synthetic_view()
+    cam = esc.Camera.for_image(eye, look, 200, 120)
+    for flags in (0, esc.ESC_RENDER_TWO_KERNELS, esc.ESC_RENDER_INDEX_ORDER):
+        renderer.reset_counters()
+        a = renderer.render(cam, 200, 120, flags=flags)
+        c1 = renderer.counters()
+        b = renderer.render(cam, 200, 120, flags=flags | esc.ESC_RENDER_NO_COUNTERS)
+        c2 = renderer.counters()
+        assert_bit_equal(b, a, f"flags {flags}: without counters")
+        assert c1 == c2 and c1["primary_rays"] == 200 * 120, (c1, c2)
