@@ -18,14 +18,14 @@ for cfg, W, H in (("c3", 3840, 2160), ("c4", 3840, 2160), ("c5", 7680, 4320)):
     cam = esc.Camera.for_image(eye, look, W, H)
     buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
     e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    e[0].record(st); r.render_rows(cam, W, H, 0, H, out_f32=buf); e[1].record(st)   # builds every list
-    r.render_rows(cam, W, H, 0, H, out_f32=buf); e[2].record(st); r.synchronize()
+    e[0].record(st); r.render_rows(cam, W, H, 0, H, out_f32=buf, flags=esc.ESC_RENDER_NO_COUNTERS); e[1].record(st)   # builds every list
+    r.render_rows(cam, W, H, 0, H, out_f32=buf, flags=esc.ESC_RENDER_NO_COUNTERS); e[2].record(st); r.synchronize()
     first, steady = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
     mv = []
     for i in range(10):  # a camera that moves every frame: per-camera tables + tile lists rebuilt
         c2 = esc.Camera.for_image((eye[0] + 0.01 * (i + 1), eye[1], eye[2]), look, W, H)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(st); r.render_rows(c2, W, H, 0, H, out_f32=buf); b.record(st); r.synchronize()
+        a.record(st); r.render_rows(c2, W, H, 0, H, out_f32=buf, flags=esc.ESC_RENDER_NO_COUNTERS); b.record(st); r.synchronize()
         mv.append(a.elapsed_time(b))
     mv.sort()
     print(f"{cfg}: upload (stage + commit incl. group build) {1e3 * (t1 - t0):.1f} ms; first frame (per-camera tables, "

@@ -16,6 +16,7 @@ r = esc.Renderer(0, stream=st)
 r.upload(esc.Scene.synthetic(cfg))
 cam = esc.Camera.for_image(*esc.synthetic_view(), W, H)
 buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
+NC = esc.ESC_RENDER_NO_COUNTERS  # what bench.py times: the ray counters are instrumentation
 variants = [("one kernel (default)", 0), ("two kernels", esc.ESC_RENDER_TWO_KERNELS),
             ("one kernel, no lists", esc.ESC_RENDER_NO_TILE_LISTS | esc.ESC_RENDER_NO_LIGHT_LISTS),
             ("two kernels, no lists", esc.ESC_RENDER_TWO_KERNELS | esc.ESC_RENDER_NO_TILE_LISTS |
@@ -28,7 +29,7 @@ for rd in range(3):
             for i in range(12):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(st)
-                r.render_rows(cam, W, H, 0, H, out_f32=buf, flags=flags)
+                r.render_rows(cam, W, H, 0, H, out_f32=buf, flags=flags | NC)
                 e1.record(st)
                 st.synchronize()
                 if i >= 2:
@@ -36,7 +37,7 @@ for rd in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             for i in range(20):
-                r.render_rows(cam, W, H, 0, H, out_f32=buf, flags=flags)
+                r.render_rows(cam, W, H, 0, H, out_f32=buf, flags=flags | NC)
             e1.record(st)
             st.synchronize()
         ms.sort()

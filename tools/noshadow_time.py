@@ -18,7 +18,7 @@ buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
 for sh in (True, False):
     ms = []
     for i in range(13):
-        r.render_rows(cam, W, H, 0, H, out_f32=buf, shadows=sh, flags=esc.ESC_RENDER_TIME_KERNELS)
+        r.render_rows(cam, W, H, 0, H, out_f32=buf, shadows=sh, flags=esc.ESC_RENDER_TIME_KERNELS | esc.ESC_RENDER_NO_COUNTERS)
         r.synchronize()
         if i >= 3:
             ms.append(r.last_kernel_ms())

@@ -14,10 +14,13 @@ r.upload(esc.Scene.synthetic(cfg))
 cam = esc.Camera.for_image(*esc.synthetic_view(), W, H)
 buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
 r.reset_counters()
-for _ in range(3):
-    r.render_rows(cam, W, H, 0, H, out_f32=buf, stage=stage, shadows=shadows, px=px)
+r.render_rows(cam, W, H, 0, H, out_f32=buf, stage=stage, shadows=shadows, px=px)  # one counted frame
 r.synchronize()
 c = r.counters()
+for _ in range(3):  # ... and three as bench.py times them (ESC_RENDER_NO_COUNTERS)
+    r.render_rows(cam, W, H, 0, H, out_f32=buf, stage=stage, shadows=shadows, px=px,
+                  flags=esc.ESC_RENDER_NO_COUNTERS)
+r.synchronize()
 print(c)
 if c['anyhit_lane_tests']:
     print('shadow lane efficiency', c['anyhit_tests'] / c['anyhit_lane_tests'])

@@ -32,11 +32,11 @@ def timed(fn, n=40):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-full = timed(lambda: r.render_strips(cam, W, H, 0, 1, out_u8=buf, shadows=cfg != "c2"))
+full = timed(lambda: r.render_strips(cam, W, H, 0, 1, out_u8=buf, shadows=cfg != "c2", flags=esc.ESC_RENDER_NO_COUNTERS))
 print(f"{cfg} whole frame {full:.1f} us; ideal share of {N}: {full / N:.1f} us")
 for name, fl in (("one kernel", 0), ("two kernels", esc.ESC_RENDER_TWO_KERNELS)):
     for S in (8, 32):
-        ts = [timed(lambda: r.render_strips(cam, W, H, k, N, out_u8=buf, shadows=cfg != "c2", strip_rows=S, flags=fl))
+        ts = [timed(lambda: r.render_strips(cam, W, H, k, N, out_u8=buf, shadows=cfg != "c2", strip_rows=S, flags=fl | esc.ESC_RENDER_NO_COUNTERS))
               for k in range(N)]
         print(f"  {name}, strips of {S:2d} rows: rank shares " + " ".join(f"{t:.1f}" for t in ts) +
               f"  max {max(ts):.1f} us")

@@ -19,6 +19,6 @@ for cfg in ("c2", "c4"):
     r.upload(esc.Scene.synthetic(cfg))
     for sh in (True, False):
         for name, h0, n in (("8 sky rows at 2100", 2104, 8), ("8 rows at 1000", 1000, 8), ("8 floor rows at 100", 104, 8), ("64 rows at 1000", 1000, 64)):
-            t = timed(lambda: r.render_rows(cam, W, H, h0, h0 + n, out_f32=buf, shadows=sh))
-            t2 = timed(lambda: r.render_rows(cam, W, H, h0, h0 + n, out_f32=buf, shadows=sh, flags=esc.ESC_RENDER_NO_LIGHT_LISTS | esc.ESC_RENDER_NO_TILE_LISTS))
+            t = timed(lambda: r.render_rows(cam, W, H, h0, h0 + n, out_f32=buf, shadows=sh, flags=esc.ESC_RENDER_NO_COUNTERS))
+            t2 = timed(lambda: r.render_rows(cam, W, H, h0, h0 + n, out_f32=buf, shadows=sh, flags=esc.ESC_RENDER_NO_LIGHT_LISTS | esc.ESC_RENDER_NO_TILE_LISTS | esc.ESC_RENDER_NO_COUNTERS))
             print(f"{cfg} shadows={sh} {name}: {t:.1f} us; without lists {t2:.1f} us")
