@@ -1357,13 +1357,14 @@ DEVINL uint8_t quantise_channel(float c) { // main.cpp:676-682 clamp > 1, int(c 
   const float cc = (c > 1.f) ? 1.f : c;
   return (uint8_t)(int)(cc * 255.f);
 }
-DEVINL void write_tile64(const RenderParams &p, const Tile<2> &T, int tid, const float (*park)[6][256]) {
+DEVINL void write_tile64(const RenderParams &p, const Tile<2> &T, int tid, const float (*park)[6][256],
+                         bool with_f32 = true) {
   constexpr int TW = 64;
   const int rows = p.n_local_rows;
   const int w0 = T.w0, lr0 = T.lr0;
   const bool full_tile = (w0 + TW <= p.W) && (lr0 + kTileH <= rows) && (T.h_tile + kTileH <= p.H);
   const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly;
-  if (p.out_f32) {
+  if (p.out_f32 && with_f32) {
     if (full_tile) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -1562,17 +1563,36 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
       }
       if (p.counters && p.shadows) n_any += wave_sum(cnt_lane); // wave-uniform
     }
-    park[q][0][tid] = r; // the pixel's slots now hold its colour
-    park[q][1][tid] = g;
-    park[q][2][tid] = b;
+    // the fp32 pixel straight from its registers: the 16 lanes of a tile row write 192 consecutive
+    // bytes, 64-byte aligned whenever W is a multiple of 16 (whole sectors; the other half of each
+    // 128-byte line follows with the lane's second pixel).  Going through the LDS slots for whole
+    // rows per store instruction cost 0.03 ms of a c4 frame in index arithmetic, LDS round trips and
+    // the barrier.  The PPM bytes (3 per pixel: 48-byte runs) keep that path.
+    if (p.out_f32) {
+      const Tile<2> Tw = tile_again2(p);
+      const int lr = Tw.lr0 + Tw.ly, w = Tw.w0 + Tw.lx0 + 16 * q;
+      if (lr < p.n_local_rows && Tw.h_tile + Tw.ly < p.H && w < p.W) {
+        float *o = p.out_f32 + ((size_t)lr * p.W + w) * 3;
+        o[0] = r;
+        o[1] = g;
+        o[2] = b;
+      }
+    }
+    if (p.out_u8) {
+      park[q][0][tid] = r; // the pixel's slots now hold its colour
+      park[q][1][tid] = g;
+      park[q][2][tid] = b;
+    }
   }
   {
     const Tile<2> Te = tile_again2(p);
     const int tid_e = Te.wave * 64 + Te.lane;
     emit_counters_n(p, tid_e, Te.lane, n_inside, n_hit, n_shadow, Te.lane == 0 ? n_any : 0ull,
                     Te.lane == 0 ? (unsigned long long)n_swept * 64ull : 0ull);
-    __syncthreads(); // every pixel's colour is in its slot
-    write_tile64(p, Te, tid_e, park);
+    if (p.out_u8) {
+      __syncthreads(); // every pixel's colour is in its slot
+      write_tile64(p, Te, tid_e, park, false);
+    }
   }
 }
 
