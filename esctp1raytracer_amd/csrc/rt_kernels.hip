@@ -428,6 +428,13 @@ template <int PX> struct Tile {
     init(p, blockIdx.x % tiles_x, blockIdx.x / tiles_x, threadIdx.x);
     wave = __builtin_amdgcn_readfirstlane(wave); // wave-uniform for the workgroup's own thread id
   }
+  // a kernel launched on a (tiles_x, tiles_y) grid: no division for the tile's coordinates (an integer
+  // division is ~25 instructions here, and k_frame asks for its tile six times over -- see tile_again2)
+  struct Grid2D {};
+  DEVINL Tile(const RenderParams &p, Grid2D) {
+    init(p, (int)blockIdx.x, (int)blockIdx.y, threadIdx.x);
+    wave = __builtin_amdgcn_readfirstlane(wave);
+  }
   // tile (tx, ty) of the band as seen by thread `tid` of a 256-thread workgroup
   DEVINL Tile(const RenderParams &p, int tx, int ty, int tid) { init(p, tx, ty, tid); }
   DEVINL void init(const RenderParams &p, int tx, int ty, int tid) {
@@ -441,7 +448,10 @@ template <int PX> struct Tile {
     // height, so lr / strip_rows == 0 and h = h0 + lr; cyclic strips (multi-GPU) jump by
     // strip_step image rows per strip.  strip_rows is a multiple of kTileH (host-checked).
     lr0 = ty * kTileH;
-    h_tile = p.h0 + (lr0 / p.strip_rows) * p.strip_step + (lr0 % p.strip_rows);
+    // (the two usual cases without a division: one contiguous band; strips of exactly one tile row)
+    if (lr0 < p.strip_rows) h_tile = p.h0 + lr0;
+    else if (p.strip_rows == kTileH) h_tile = p.h0 + ty * p.strip_step;
+    else h_tile = p.h0 + (lr0 / p.strip_rows) * p.strip_step + (lr0 % p.strip_rows);
   }
 };
 
@@ -1310,11 +1320,10 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
 // one image row.  Same functions as the two-kernel path (primary_closest, shadow_sweep_smem,
 // phong_add): same arithmetic, same image.  ESC_RENDER_TWO_KERNELS keeps k_primary + k_shade.
 // ---------------------------------------------------------------------------------------
-DEVINL Tile<2> tile_again2(const RenderParams &p) { // (see tile_again)
+DEVINL Tile<2> tile_again2(const RenderParams &p) { // (see tile_again); k_frame's (tiles_x, tiles_y) grid
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));
-  const int tiles_x = (p.W + 63) / 64;
-  Tile<2> T(p, blockIdx.x % tiles_x, blockIdx.x / tiles_x, t);
+  Tile<2> T(p, (int)blockIdx.x, (int)blockIdx.y, t);
   T.wave = __builtin_amdgcn_readfirstlane(T.wave);
   return T;
 }
@@ -1423,7 +1432,7 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[16];
   const int tid = threadIdx.x;
   { // ---- camera.h:31-34 + main.cpp:722: both pixels of every lane (k_primary's body)
-    const Tile<2> T(p);
+    const Tile<2> T(p, Tile<2>::Grid2D{});
     const int h = T.h_tile + T.ly;
     f3 dir[2];
     Hit hit[2];
@@ -2041,15 +2050,15 @@ extern "C" int esc_launch_render(const esc::RenderParams *p, int stage, int px, 
     if (between) (void)hipEventRecord(between, stream);
     hipLaunchKernelGGL((esc::k_shade<esc::STAGE_LDS>), dim3(shade_grid), dim3(256), 0, stream, *p);
   } else if (!two_kernels && !between) { // the whole frame in one kernel (k_frame)
-    const int grid = ((p->W + 63) / 64) * tiles_y;
+    const dim3 grid((unsigned)((p->W + 63) / 64), (unsigned)tiles_y); // (x, y) = the tile: Tile<2>::Grid2D
     const bool grp = p->use_filter && (p->sg.n_grp > 0 || p->tg.n_grp > 0);
     const bool tgrp = p->use_filter && p->tg.n_grp > 0;
     if (tgrp)
-      hipLaunchKernelGGL((esc::k_frame<true, true>), dim3(grid), dim3(256), 0, stream, *p);
+      hipLaunchKernelGGL((esc::k_frame<true, true>), grid, dim3(256), 0, stream, *p);
     else if (grp)
-      hipLaunchKernelGGL((esc::k_frame<true, false>), dim3(grid), dim3(256), 0, stream, *p);
+      hipLaunchKernelGGL((esc::k_frame<true, false>), grid, dim3(256), 0, stream, *p);
     else
-      hipLaunchKernelGGL((esc::k_frame<false, false>), dim3(grid), dim3(256), 0, stream, *p);
+      hipLaunchKernelGGL((esc::k_frame<false, false>), grid, dim3(256), 0, stream, *p);
   } else {
     launch_primary<esc::STAGE_SMEM, v2f, 1>(p, stream); // always 2 px: see esc_launch_primary_only
     if (between) (void)hipEventRecord(between, stream);
