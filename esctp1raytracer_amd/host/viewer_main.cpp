@@ -139,6 +139,7 @@ int main(int argc, char *argv[]) {
   if (flat) opts.stage = ESC_STAGE_BVH; // tree build happens inside the timed region, like the
                                         // reference's buildBVH sits before its render clock
   if (bvh_tree) opts.flags |= ESC_RENDER_BVH_HEURISTIC_PADS;
+  opts.flags |= ESC_RENDER_NO_COUNTERS; // the viewer prints no ray statistics: no instrumentation in its frames
 
   // Device set-up is to this program what dynamic linking is to the reference: it happens before
   // the clock.  One device: context, scene tables in HBM and the kernels' code object (a 2x2
