@@ -953,6 +953,26 @@ DEVINL void shadow_sweep_smem(const RenderParams &p, RepackLds &R, int tid, int 
   mi = __float_as_int(R.keep[7][tid]);
 }
 
+// "Did any wave of the workgroup raise its hand?" with ONE barrier (__syncthreads_or takes three and an
+// LDS reduction).  Four LDS words used in turn: vote k writes word k & 3 before the barrier and reads
+// it after; on its way in every wave clears the NEXT word, (k + 1) & 3 -- last read before barrier
+// k - 2 ... k - 1 at the latest, and written again only after barrier k.  `word` must be zero before
+// the first vote (wg_vote_init + one barrier at the top of the kernel); `mine` is wave-uniform.
+DEVINL void wg_vote_init(int *word) {
+  if (threadIdx.x < 4) word[threadIdx.x] = 0;
+  __syncthreads();
+}
+DEVINL bool wg_vote_any(int *word, int &k, bool mine) {
+  const int cur = k & 3;
+  ++k;
+  if ((threadIdx.x & 63u) == 0) {
+    word[(cur + 1) & 3] = 0;
+    if (mine) word[cur] = 1;
+  }
+  __syncthreads();
+  return word[cur] != 0;
+}
+
 // ---- the shadow rays of light li when LISTS serve them: no re-packing, no LDS, each wave on its own.
 // shadow_sweep_smem re-packs the workgroup's undecided rays between segments of long sweeps; with the
 // light lists (rt_lists.h) a sweep is a few batches, and the parking / re-packing / barriers around
@@ -1066,6 +1086,9 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
   constexpr int NV = 1;
   constexpr int TW = 32;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE == STAGE_LDS ? kLdsChunkBytes : 16];
+  __shared__ int vote_word[4];
+  int vote_k = 0;
+  if (STAGE == STAGE_SMEM) wg_vote_init(vote_word);
   __shared__ float lds_px[TW * kTileH * 3];
   __shared__ RepackLds lds_rays; // SMEM stage only
 
@@ -1222,7 +1245,7 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
           int go = 0, sw = 0;
           bool tg = false, sgp = false;
           const bool ok = shadow_wave_lists<TGRP>(p, li, ro, rL, af, go, tg, sgp, sw);
-          if (!__syncthreads_or(ok ? 0 : 1)) {
+          if (!wg_vote_any(vote_word, vote_k, !ok)) {
             a[0].kocc = af.kocc;
             a[0].tocc = af.tocc;
             grp_open = go;
@@ -1430,6 +1453,9 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
   __shared__ RepackLds lds_rays;
   __shared__ float park[2][6][256]; // per pixel q of thread t: dir xyz, t, v, idx; later r, g, b
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[16];
+  __shared__ int vote_word[4];
+  int vote_k = 0;
+  wg_vote_init(vote_word);
   const int tid = threadIdx.x;
   { // ---- camera.h:31-34 + main.cpp:722: both pixels of every lane (k_primary's body)
     const Tile<2> T(p, Tile<2>::Grid2D{});
@@ -1535,7 +1561,7 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
           int go = 0, sw = 0;
           bool tg = false, sgp = false;
           const bool ok = shadow_wave_lists<TGRP>(p, li, ro, rL, af, go, tg, sgp, sw);
-          if (!__syncthreads_or(ok ? 0 : 1)) { // every wave of the workgroup was served
+          if (!wg_vote_any(vote_word, vote_k, !ok)) { // every wave of the workgroup was served
             a[0].kocc = af.kocc;
             a[0].tocc = af.tocc;
             grp_open = go;
