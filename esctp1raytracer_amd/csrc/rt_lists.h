@@ -85,6 +85,41 @@ DEVINL void list_rect(const RenderParams &p, const TileLists &L, int w0, int w1,
   }
 }
 
+// ... and the same for a CONVEX region given by its support along three directions as well: a tile
+// none of whose pixels can lie inside [lo_a, hi_a] along some direction n_a is left out.  (The
+// triangle's region is the convex hull of 12 small rectangles; its bounding box alone hands a large
+// triangle seen at an angle to twice the tiles it touches.)  Tiles are taken one pixel larger all
+// round, like the rectangle's own floor / ceil; a NaN anywhere compares false and keeps the tile.
+struct HullAxes {
+  double nx[3], ny[3], lo[3], hi[3];
+};
+DEVINL void list_rect_hull(const RenderParams &p, const TileLists &L, int w0, int w1, int h0, int h1, int id,
+                           int lane, const HullAxes &A) {
+  const int tx0 = w0 >> 5, tx1 = w1 >> 5, j0 = h0 >> 2, j1 = h1 >> 2;
+  if ((long long)(tx1 - tx0 + 1) * (j1 - j0 + 1) > kTileMaxSpan) {
+    if (lane == 0) list_global(L, id);
+    return;
+  }
+  const int nx = tx1 - tx0 + 1, n = nx * (j1 - j0 + 1);
+  for (int k = lane; k < n; k += 64) {
+    const int j = j0 + k / nx, tx = tx0 + k % nx;
+    const int r4 = band_tile_row(p, j);
+    if (r4 < 0) continue;
+    const double x0 = 32.0 * tx - 1.0, x1 = 32.0 * tx + 32.0, y0 = 4.0 * j - 1.0, y1 = 4.0 * j + 4.0;
+    bool outside = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double ax0 = A.nx[a] * x0, ax1 = A.nx[a] * x1, ay0 = A.ny[a] * y0, ay1 = A.ny[a] * y1;
+      const double tmin = fmin(ax0, ax1) + fmin(ay0, ay1), tmax = fmax(ax0, ax1) + fmax(ay0, ay1);
+      outside |= (tmax < A.lo[a]) | (tmin > A.hi[a]);
+    }
+    if (outside) continue;
+    const int tile = r4 * L.tiles_x + tx;
+    const int slot = atomicAdd(&L.cnt[tile], 1);
+    if (slot < kTileListCap) L.ids[(size_t)tile * kTileListCap + slot] = id;
+  }
+}
+
 // one wave per slot of the group-sorted sphere table
 __global__ void __launch_bounds__(256) k_bin_spheres(const RenderParams p) {
   const int s = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
@@ -249,6 +284,31 @@ __global__ void __launch_bounds__(256) k_bin_triangles(const RenderParams p) {
     if (lane == 0) list_global(L, k);
     return;
   }
+  // the hull of the 12 corner rectangles along the normals of the projected triangle's three edges
+  // (any direction would do for the argument; these are the ones that cut): vertex i's image is
+  // taken as the mean of its four corners' centres (lanes 4 i .. 4 i + 3)
+  const double ccx = 0.5 * (ext[0] + ext[1]), ccy = 0.5 * (ext[2] + ext[3]);
+  const double chx = 0.5 * (ext[1] - ext[0]), chy = 0.5 * (ext[3] - ext[2]);
+  double vx[3], vy[3];
+  for (int i = 0; i < 3; ++i) {
+    vx[i] = 0.25 * (__shfl(ccx, 4 * i) + __shfl(ccx, 4 * i + 1) + __shfl(ccx, 4 * i + 2) + __shfl(ccx, 4 * i + 3));
+    vy[i] = 0.25 * (__shfl(ccy, 4 * i) + __shfl(ccy, 4 * i + 1) + __shfl(ccy, 4 * i + 2) + __shfl(ccy, 4 * i + 3));
+  }
+  HullAxes HA;
+  for (int a = 0; a < 3; ++a) {
+    const int b = (a + 1) % 3;
+    HA.nx[a] = vy[b] - vy[a];
+    HA.ny[a] = vx[a] - vx[b];
+    const double c = HA.nx[a] * ccx + HA.ny[a] * ccy, r = fabs(HA.nx[a]) * chx + fabs(HA.ny[a]) * chy;
+    double lo = c - r, hi = c + r;
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = fmin(lo, __shfl_xor(lo, off));
+      hi = fmax(hi, __shfl_xor(hi, off));
+    }
+    const double pad = 1e-6 * (fabs(lo) + fabs(hi)) + 1e-6; // the arithmetic of this test itself
+    HA.lo[a] = lo - pad;
+    HA.hi[a] = hi + pad;
+  }
   for (int off = 32; off > 0; off >>= 1) { // union over the lanes (12 distinct corners, repeated)
     ext[0] = fmin(ext[0], __shfl_xor(ext[0], off));
     ext[1] = fmax(ext[1], __shfl_xor(ext[1], off));
@@ -257,7 +317,7 @@ __global__ void __launch_bounds__(256) k_bin_triangles(const RenderParams p) {
   }
   int w0, w1, h0, h1;
   if (extent_rect(ext, p.W, p.H, w0, w1, h0, h1) == 2) return; // off screen
-  list_rect(p, L, w0, w1, h0, h1, k, lane);
+  list_rect_hull(p, L, w0, w1, h0, h1, k, lane, HA);
 }
 
 // (E_t): one workgroup per tile row: p . n = fA + s fH + t fV is affine, so over the row's t range the band
