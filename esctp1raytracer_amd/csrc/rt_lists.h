@@ -242,6 +242,24 @@ __global__ void __launch_bounds__(256) k_bin_triangles(const RenderParams p) {
     if (lane == 0) list_global(L, k);
     return;
   }
+  // Statement (K) of rt_brute.h trades the two halves (as the triangle light lists do per light): with
+  // the escape threshold tau_t / k an accepted hit lies within k rho_t of its triangle in its plane,
+  // and the escape needs the camera within H_t(tau_t / k) of the plane.  Per camera each triangle takes
+  // the SMALLEST k of 1/8, 1/4, 1/2, 1 at which this camera cannot take the escape at all: an eighth
+  // of the dilation for nearly every triangle (the region is then the triangle itself, a little
+  // grown, instead of a shape three times its size); a triangle the camera is nearly in the plane of
+  // keeps k = 1 and leaves its entry for k_bin_tri_escape.
+  double kK = 1.0;
+  if (!E.possible) {
+    for (int tr = 0; tr < 3; ++tr) {
+      const float kc = 0.125f * (float)(1 << tr);
+      const TriEscape Ec = tri_escape(T, mk(p.origin[0], p.origin[1], p.origin[2]), kc);
+      if (Ec.bounded && !Ec.possible) {
+        kK = (double)kc;
+        break;
+      }
+    }
+  }
   if (E.possible && lane == 0) { // the camera is nearly in this plane: k_bin_tri_escape bins the band
     const int slot = atomicAdd(&L.hdr[1], 1);
     if (slot < kTileEscCap) {
@@ -265,7 +283,7 @@ __global__ void __launch_bounds__(256) k_bin_triangles(const RenderParams p) {
   const double at = (fabs(v0[0]) + fabs(v0[1]) + fabs(v0[2])) + (fabs(e1[0]) + fabs(e1[1]) + fabs(e1[2])) +
                     (fabs(e2[0]) + fabs(e2[1]) + fabs(e2[2]));
   const double slack = 0x1p-20 * at + 0x1p-60;
-  const double rp = rho * (1.0 + 1e-5) + slack;
+  const double rp = kK * rho * (1.0 + 1e-5) + slack;
   const double ea[3] = {e1[0] / l1, e1[1] / l1, e1[2] / l1};
   double eb[3];
   cross3(n1, ea, eb);
