@@ -278,6 +278,11 @@ struct alignas(16) TileEsc { // one triangle whose "nearly parallel" escape rays
   double fA, fH, fV;         // rays with |p . n| <= kp |p|; p . n = fA + s fH + t fV is affine in the
   float kp;                  // image-plane coordinates (s, t) of p = A + s H + t V
   int32_t id;                // slot in the sorted table
+  // ... AND |p . m_u| <= kpu |p|, |p . m_v| <= kpv |p| (rt_lists.h "escape rays pass the edges' planes
+  // too"): unit normals of the planes through the ray origin and an edge line, same affine form
+  double uA, uH, uV, vA, vH, vV;
+  float kpu, kpv;
+  int32_t pad[2];
 };
 struct TileLists {
   int32_t *hdr;      // kTileHdrInts

@@ -157,6 +157,7 @@ struct TriEscape {
   f3 nh;         // unit normal
   float beta;    // tau / |n1| for this origin distance
   float H;       // the origin must lie within H of the plane
+  float U, V;    // an escape accept has |un*| <= U, |vn*| <= V (the exact numerators; see k_bin_triangles)
 };
 // (P) for ray origins with |origin - v0|_1 <= at: beta and H grow with at, so a bound on at gives a
 // bound for every origin it covers.  `pad` out: the slot holds no triangle (all zeros: det == 0).
@@ -167,6 +168,7 @@ DEVINL TriEscape tri_escape_at(const DevTri &T, float at, float slack_k, bool &p
   E.nh = mk(0.f, 0.f, 0.f);
   E.beta = 0.f;
   E.H = 0.f;
+  E.U = E.V = __builtin_huge_valf();
   pad = false;
   const float u = 0x1p-24f;
   const f3 e1 = ld3(T.e1), e2 = ld3(T.e2);
@@ -193,6 +195,8 @@ DEVINL TriEscape tri_escape_at(const DevTri &T, float at, float slack_k, bool &p
   E.H = (fmaxf(V / l1, U / l2) + at * tau / nn) * (2.f * l1 * l2 / nn) * (1.f / 0.99f);
   E.nh = n1 * (1.f / nn);
   E.beta = tau / nn;
+  E.U = U;
+  E.V = V;
   E.bounded = (E.nh.x == E.nh.x) && (E.nh.y == E.nh.y) && (E.nh.z == E.nh.z) && (E.beta == E.beta) &&
               (E.H == E.H);
   return E;
@@ -276,6 +280,33 @@ __global__ void __launch_bounds__(256) k_bin_triangles(const RenderParams p) {
       X.fV = dot3(V, nh);
       X.kp = E.beta * 1.0001f + 0x1p-20f; // fp32 beta and normal, |d| - 1
       X.id = k;
+      // Escape rays pass the edges' planes too.  An accept through the escape has |det*| < tau, hence
+      // |det_ref| <= tau + ed, and it needs 0 < un / det, vn / det <= 1 + 4u in the reference's own
+      // numerators (rt_brute.h "Triangle pre-filter"): |un*| <= (tau + ed)(1 + 4u) + eu = U, |vn*| <= V
+      // (tri_escape_at's U, V, built on |tvec|_1 |e|_1 >= the products the bounds are stated in).  The
+      // exact numerators are triple products of the reference's direction d:
+      //     un* = tvec . (d x e2) = d . (e2 x tvec),      vn* = d . (tvec x e1),
+      // tvec = fl(o - v0) as the reference rounds it -- two more planes through the ray origin, each
+      // holding an edge line, that d is nearly parallel to.  Their bands are affine in (s, t) like the
+      // first; a tile gets the triangle only where all three cross it: the neighbourhood of the
+      // triangle's own image instead of a stripe across the frame.
+      const f3 tvf = mk(p.origin[0], p.origin[1], p.origin[2]) - ld3(T.v0);
+      const double tvd[3] = {tvf.x, tvf.y, tvf.z};
+      double mu[3], mv[3];
+      cross3(e2, tvd, mu);
+      cross3(tvd, e1, mv);
+      const double lu = sqrt(dot3(mu, mu)), lv = sqrt(dot3(mv, mv));
+      const double ku = (double)E.U / lu * 1.0001 + 0x1p-20, kv = (double)E.V / lv * 1.0001 + 0x1p-20;
+      const bool use_u = lu > 0.0 && ku < 0.5, use_v = lv > 0.0 && kv < 0.5; // (NaN: no constraint)
+      X.uA = use_u ? dot3(A, mu) / lu : 0.0;
+      X.uH = use_u ? dot3(Hh, mu) / lu : 0.0;
+      X.uV = use_u ? dot3(V, mu) / lu : 0.0;
+      X.kpu = use_u ? (float)(ku * (1.0 + 0x1p-20)) : 2.f; // |p . 0| <= 2 |p|: every tile
+      X.vA = use_v ? dot3(A, mv) / lv : 0.0;
+      X.vH = use_v ? dot3(Hh, mv) / lv : 0.0;
+      X.vV = use_v ? dot3(V, mv) / lv : 0.0;
+      X.kpv = use_v ? (float)(kv * (1.0 + 0x1p-20)) : 2.f;
+      X.pad[0] = X.pad[1] = 0;
       L.esc[slot] = X;
     }
   }
@@ -373,14 +404,22 @@ __global__ void __launch_bounds__(256) k_bin_tri_escape(const RenderParams p) {
     __syncthreads();
     for (int k = tid; k < n_esc; k += 256) {
       const TileEsc X = L.esc[k];
-      int tx0, tx1;
-      if (!band_row_tiles_with(p, cam, L.tiles_x, pmax_row, t0, t1, X.fA, X.fH, X.fV, (double)X.kp, tx0, tx1)) {
+      int tx0, tx1, ux0, ux1, vx0, vx1;
+      if (!band_row_tiles_with(p, cam, L.tiles_x, pmax_row, t0, t1, X.fA, X.fH, X.fV, (double)X.kp, tx0, tx1) ||
+          !band_row_tiles_with(p, cam, L.tiles_x, pmax_row, t0, t1, X.uA, X.uH, X.uV, (double)X.kpu, ux0, ux1) ||
+          !band_row_tiles_with(p, cam, L.tiles_x, pmax_row, t0, t1, X.vA, X.vH, X.vV, (double)X.kpv, vx0, vx1)) {
         L.hdr[2] = 1; // nothing can be said
         continue;
       }
+      tx0 = max(tx0, max(ux0, vx0)); // the three bands' tiles of this row
+      tx1 = min(tx1, min(ux1, vx1));
       for (int tx = max(tx0, c0); tx <= min(tx1, c1 - 1); ++tx) {
         tile_st(p, cam, tx, h, st);
-        if (!tile_band_hit(st, s_pmax[tx - c0], X.fA, X.fH, X.fV, (double)X.kp)) continue;
+        const double pm = s_pmax[tx - c0];
+        if (!tile_band_hit(st, pm, X.fA, X.fH, X.fV, (double)X.kp) ||
+            !tile_band_hit(st, pm, X.uA, X.uH, X.uV, (double)X.kpu) ||
+            !tile_band_hit(st, pm, X.vA, X.vH, X.vV, (double)X.kpv))
+          continue;
         const int tile = r4 * L.tiles_x + tx;
         const int slot = atomicAdd(&L.cnt[tile], 1);
         if (slot < kTileListCap) L.ids[(size_t)tile * kTileListCap + slot] = X.id;
