@@ -31,10 +31,15 @@ def random_scene(seed):
     n_sph = 0
     if kind in (0, 1, 3):
         n_sph = int(10.0 ** rng.uniform(1.0, 3.3))
+    flat_y = None
     if kind in (1, 2, 3):
         n = int(rng.integers(3, 40 if kind == 2 else 14))
         c = origin + rng.uniform(-0.3, 0.3, 3) * box
-        geoms.append({"vertex": _patch(rng, n, box * rng.uniform(0.3, 1.0), c, box * 10.0 ** rng.uniform(-3, -0.7)),
+        rough = box * 10.0 ** rng.uniform(-3, -0.7)
+        if seed % 9 == 0:  # a flat patch, the camera (below) nearly in its plane: escape entries
+            rough = 0.0 if seed % 18 == 0 else box * 10.0 ** rng.uniform(-7, -4)
+            flat_y = float(c[1])
+        geoms.append({"vertex": _patch(rng, n, box * rng.uniform(0.3, 1.0), c, rough),
                       "face_index": np.arange(6 * n * n).reshape(-1, 3), "material": ol.WHITE})
     if kind == 3 or seed % 5 == 0:  # loose triangles of every size, slivers included
         k = int(rng.integers(4, 200))
@@ -65,6 +70,10 @@ def random_scene(seed):
     d = ol.scene_dict(geoms, sph, mats)
     eye = origin + rng.uniform(-1.2, 1.2, 3) * box * (0.6 if seed % 2 else 1.5)
     look = origin + rng.uniform(-0.5, 0.5, 3) * box
+    if flat_y is not None:  # within 1e-7 .. 1e-3 of the scene's size of the patch's plane, looking along it
+        off = box * 10.0 ** rng.uniform(-7, -3) * rng.choice([-1.0, 1.0])
+        eye[1] = flat_y + off
+        look[1] = flat_y + off * rng.uniform(-2, 2)
     if np.linalg.norm(look - eye) < 1e-3 * box:
         look = eye + np.array([0.0, 0.0, -box])
     W = int(rng.integers(33, 300))
