@@ -17,7 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 r = esc.Renderer(0)
 off = esc.ESC_RENDER_NO_TILE_LISTS | esc.ESC_RENDER_NO_LIGHT_LISTS
-bad = lit = listed = served = 0
+bad = lit = listed = served = cones = 0
 for seed in range(first, first + n):
     d, eye, look, W, H, vfov = random_scene(seed)
     r.upload(ol.scene_to_product(d))
@@ -32,10 +32,11 @@ for seed in range(first, first + n):
     lit += 1 if a.any() else 0
     listed += 1 if any(s is not None and s["off"] == 0 for s in st[:2]) else 0
     served += 1 if any(s is not None and s["off"] == 0 for s in st[2:]) else 0
+    cones += 1 if (st[1] is not None and st[1]["cones"] > 0) else 0
     if nd:
         bad += 1
         print(f"DIFFERENCE seed={seed} pixels={nd} W={W} H={H} eye={eye} look={look} vfov={vfov}", flush=True)
     if (seed - first) % 100 == 99:
         print(f"... {seed - first + 1} scenes, {bad} differ", flush=True)
 print(f"{n} scenes from seed {first}: {lit} with lit pixels, {listed} with tile lists, {served} with light lists, "
-      f"{bad} with a difference")
+      f"{cones} with escape entries, {bad} with a difference")
