@@ -25,6 +25,7 @@ extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_
                                   esc::DevTriF *tri_f, esc::DevTriPF *tri_pf, esc::DevSphP *sph_p,
                                   esc::DevSphF *sph_f, const esc::SphGroups *sg,
                                   const esc::TriGroups *tg, hipStream_t stream);
+extern "C" int esc_launch_face_normals(const esc::DevTri *tri, esc::DevTriFace *out, int n, hipStream_t stream);
 extern "C" int esc_launch_prepare_bvh(const esc::DevTri *tri, esc::DevTriP *tri_p, int n_tri,
                                       const esc::DevSph *sph, esc::DevSphP *sph_p, int n_sph,
                                       float ox, float oy, float oz, hipStream_t stream);
@@ -64,6 +65,7 @@ struct esc_context {
   esc::DevTri *d_tri = nullptr;
   esc::DevTriP *d_tri_p = nullptr;
   esc::DevTriN *d_tri_n = nullptr;
+  esc::DevTriFace *d_tri_face = nullptr;
   esc::DevSph *d_sph = nullptr;
   esc::DevSphP *d_sph_p = nullptr;
   esc::DevSphPair *d_sph2 = nullptr;
@@ -832,6 +834,14 @@ int commit(esc_context *ctx, const Staged &s) {
   ctx->shadow_rho_max = (float)rho;
   if ((rc = upload_vec(ctx->d_tri, s.tri, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_tri_n, s.tri_n, ctx->stream))) return rc;
+  if ((rc = alloc_dev(ctx->d_tri_face, s.tri.size()))) return rc;
+  if (!s.tri.empty()) {
+    const int e = esc_launch_face_normals(ctx->d_tri, ctx->d_tri_face, (int)s.tri.size(), ctx->stream);
+    if (e) {
+      set_error(std::string("k_prepare_face_normals launch: ") + hipGetErrorString((hipError_t)e));
+      return ESC_ERR_HIP;
+    }
+  }
   if ((rc = upload_vec(ctx->d_sph, s.sph, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph2, sph2, ctx->stream))) return rc;
   if ((rc = upload_vec(ctx->d_sph_mat, s.sph_mat, ctx->stream))) return rc;
@@ -1026,7 +1036,7 @@ void esc_context_destroy(esc_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,        ctx->d_sph,      ctx->d_sph_p,
+  void *ptrs[] = {ctx->d_tri,    ctx->d_tri_p,  ctx->d_tri_n,  ctx->d_tri_face,      ctx->d_sph,      ctx->d_sph_p,
                   ctx->d_sph2,   ctx->d_sph_f, ctx->d_sph2_f, ctx->d_sph2_ord, ctx->d_sph2_f_ord, ctx->d_tri_f, ctx->d_tri_pf, ctx->d_tri2_pf,
                   ctx->d_tri2_f, const_cast<esc::DevSph *>(ctx->sg.sorted),
                   const_cast<esc::DevSphGroup *>(ctx->sg.grp), const_cast<esc::DevIdx4 *>(ctx->sg.orig),
@@ -1370,6 +1380,7 @@ int render_local_rows(esc_context *ctx, const esc_camera *cam, int32_t W, int32_
   p.tri = ctx->d_tri;
   p.tri_p = ctx->d_tri_p;
   p.tri_n = ctx->d_tri_n;
+  p.tri_face = ctx->d_tri_face;
   p.sph = ctx->d_sph;
   p.sph_p = ctx->d_sph_p;
   p.sph2 = ctx->d_sph2;

@@ -186,6 +186,13 @@ struct DevTriN {
   float n1[3];
   float n2[3];
 };
+// main.cpp:728-731 hoisted (liberty 1): normalize(cross(e1, e2)) is a constant of the triangle -- the same
+// fp32 operations, once per scene (k_prepare_face_normals) instead of once per hit pixel -- with the
+// geometry id beside it, so the shading half reads 16 bytes per hit instead of the 48-byte record
+struct alignas(16) DevTriFace {
+  float n[3];
+  int32_t geom;
+};
 
 // quirk S2 (main.cpp:748-754): the light sample is light.vertex[faceID] itself; the
 // candidate points (first n_faces vertices of the light geometry, each "+ 0.0f") are
@@ -477,6 +484,7 @@ struct RenderParams {
   const DevTri *tri;
   const DevTriP *tri_p;
   const DevTriN *tri_n; // nullptr when no geometry has normals
+  const DevTriFace *tri_face; // n_tri records (k_frame)
   const DevSph *sph;
   const DevSphP *sph_p;
   const DevSphPair *sph2;    // ceil(n_sph / 2) records

@@ -1506,9 +1506,9 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
       n_hit += has_hit ? 1u : 0u;
       if (has_hit) {
         if (idx < p.n_tri) {
-          const DevTri Tr = p.tri[idx];
-          N = normalize(cross(ld3(Tr.e1), ld3(Tr.e2))); // :728-731
-          mi = Tr.geom;
+          const DevTriFace Tf = p.tri_face[idx]; // :728-731, hoisted (k_prepare_face_normals)
+          N = mk(Tf.n[0], Tf.n[1], Tf.n[2]);
+          mi = Tf.geom;
           if (p.mat[mi].has_normals) { // :733-738 with u == 0 (quirk S1)
             const DevTriN Q = p.tri_n[idx];
             const float u = 0.f, v = park[q][4][tid];
@@ -1908,6 +1908,26 @@ extern "C" int esc_launch_assemble(const void *gathered, void *frame, size_t ran
 // ---------------------------------------------------------------------------------------
 // host-side launchers (called from rt_capi.cpp)
 // ---------------------------------------------------------------------------------------
+namespace esc {
+__global__ void __launch_bounds__(256) k_prepare_face_normals(const DevTri *tri, DevTriFace *out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const DevTri Tr = tri[i];
+  const f3 N = normalize(cross(ld3(Tr.e1), ld3(Tr.e2))); // main.cpp:728-731, the shading kernels' own line
+  DevTriFace F;
+  F.n[0] = N.x;
+  F.n[1] = N.y;
+  F.n[2] = N.z;
+  F.geom = Tr.geom;
+  out[i] = F;
+}
+} // namespace esc
+extern "C" int esc_launch_face_normals(const esc::DevTri *tri, esc::DevTriFace *out, int n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(esc::k_prepare_face_normals, dim3((n + 255) / 256), dim3(256), 0, stream, tri, out, n);
+  return (int)hipGetLastError();
+}
+
 extern "C" int esc_launch_prepare(const esc::RenderParams *p, esc::DevTriP *tri_p,
                                   esc::DevTriF *tri_f, esc::DevTriPF *tri_pf, esc::DevSphP *sph_p,
                                   esc::DevSphF *sph_f, const esc::SphGroups *sg,
