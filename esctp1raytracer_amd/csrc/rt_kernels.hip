@@ -1338,10 +1338,12 @@ __global__ void __launch_bounds__(256, STAGE == STAGE_LDS ? 4 : (TGRP ? 5 : 6)) 
 // pixel (two divides, a square root and three more divides each), one launch.  The two halves
 // still want different register budgets; they meet through LDS: after the sweep every lane parks
 // dir, t, v, idx of both pixels (12 KB per workgroup) and the shading loop -- not unrolled, so one
-// copy of its code -- picks one pixel up at a time; the finished colours go back into the same
-// slots and the tile is stored from there, each store instruction writing consecutive dwords of
-// one image row.  Same functions as the two-kernel path (primary_closest, shadow_sweep_smem,
-// phong_add): same arithmetic, same image.  ESC_RENDER_TWO_KERNELS keeps k_primary + k_shade.
+// copy of its code -- picks one pixel up at a time and stores its finished colour straight from
+// registers: the 16 lanes of a tile row write 192 consecutive, 64-byte aligned bytes of fp32 (48 of
+// PPM bytes).  (Collecting the tile in LDS for whole-row store instructions cost 0.03 ms of a c4
+// frame in index arithmetic, LDS round trips and a barrier.)  Same functions as the two-kernel path
+// (primary_closest, shadow_sweep_smem, phong_add): same arithmetic, same image.
+// ESC_RENDER_TWO_KERNELS keeps k_primary + k_shade.
 // ---------------------------------------------------------------------------------------
 DEVINL Tile<2> tile_again2(const RenderParams &p) { // (see tile_again); k_frame's (tiles_x, tiles_y) grid
   int t = threadIdx.x;
@@ -1378,80 +1380,15 @@ DEVINL void emit_counters_n(const RenderParams &p, int tid, int lane, uint32_t n
     atomicAdd(&p.counters[(blockIdx.x % kCounterSets) * 8 + tid], wg_cnt[tid]);
 }
 
-// the 64 x 8 tile of k_frame out of its LDS slots: park[q][c][thread] holds channel c of pixel q of
-// that thread.  Pixel (row, x) of the tile belongs to wave (row / 4) * 2 + x / 32, lane (row % 4) *
-// 16 + x % 16, pixel q = (x / 16) % 2 (the Tile<2> layout).  Called by all 256 threads after a barrier.
-DEVINL int tile64_owner(int row, int x, int &q) {
-  q = (x >> 4) & 1;
-  return (((row >> 2) * 2 + (x >> 5)) << 6) + ((row & 3) << 4) + (x & 15);
-}
 DEVINL uint8_t quantise_channel(float c) { // main.cpp:676-682 clamp > 1, int(c * 255)
   const float cc = (c > 1.f) ? 1.f : c;
   return (uint8_t)(int)(cc * 255.f);
-}
-DEVINL void write_tile64(const RenderParams &p, const Tile<2> &T, int tid, const float (*park)[6][256],
-                         bool with_f32 = true) {
-  constexpr int TW = 64;
-  const int rows = p.n_local_rows;
-  const int w0 = T.w0, lr0 = T.lr0;
-  const bool full_tile = (w0 + TW <= p.W) && (lr0 + kTileH <= rows) && (T.h_tile + kTileH <= p.H);
-  const int lr = T.lr0 + T.ly, h = T.h_tile + T.ly;
-  if (p.out_f32 && with_f32) {
-    if (full_tile) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int idx = tid + 256 * i; // 0 .. 1535
-        const int row = idx / (TW * 3), col = idx % (TW * 3);
-        int q;
-        const int own = tile64_owner(row, col / 3, q);
-        p.out_f32[((size_t)(lr0 + row) * p.W + w0) * 3 + col] = park[q][col % 3][own];
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int w = T.w0 + T.lx0 + 16 * q;
-        if (lr < rows && h < p.H && w < p.W) {
-          const size_t o = ((size_t)lr * p.W + w) * 3;
-          p.out_f32[o + 0] = park[q][0][tid];
-          p.out_f32[o + 1] = park[q][1][tid];
-          p.out_f32[o + 2] = park[q][2][tid];
-        }
-      }
-    }
-  }
-  if (p.out_u8) {
-    if (full_tile && (p.W & 3) == 0) {
-      constexpr int ROW_DW = TW * 3 / 4; // 48 dwords per tile row
-      for (int d = tid; d < ROW_DW * kTileH; d += 256) {
-        const int row = d / ROW_DW, cb = (d % ROW_DW) * 4;
-        uint32_t word = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          int q;
-          const int own = tile64_owner(row, (cb + k) / 3, q);
-          word |= (uint32_t)quantise_channel(park[q][(cb + k) % 3][own]) << (8 * k);
-        }
-        *reinterpret_cast<uint32_t *>(p.out_u8 + ((size_t)(lr0 + row) * p.W + w0) * 3 + cb) = word;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int w = T.w0 + T.lx0 + 16 * q;
-        if (lr < rows && h < p.H && w < p.W) {
-          const size_t o = ((size_t)lr * p.W + w) * 3;
-          p.out_u8[o + 0] = quantise_channel(park[q][0][tid]);
-          p.out_u8[o + 1] = quantise_channel(park[q][1][tid]);
-          p.out_u8[o + 2] = quantise_channel(park[q][2][tid]);
-        }
-      }
-    }
-  }
 }
 
 template <bool GRP, bool TGRP>
 __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams p) {
   __shared__ RepackLds lds_rays;
-  __shared__ float park[2][6][256]; // per pixel q of thread t: dir xyz, t, v, idx; later r, g, b
+  __shared__ float park[2][6][256]; // per pixel q of thread t: dir xyz, t, v, idx
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[16];
   __shared__ int vote_word[4];
   int vote_k = 0;
@@ -1600,9 +1537,7 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
     }
     // the fp32 pixel straight from its registers: the 16 lanes of a tile row write 192 consecutive
     // bytes, 64-byte aligned whenever W is a multiple of 16 (whole sectors; the other half of each
-    // 128-byte line follows with the lane's second pixel).  Going through the LDS slots for whole
-    // rows per store instruction cost 0.03 ms of a c4 frame in index arithmetic, LDS round trips and
-    // the barrier.  The PPM bytes (3 per pixel: 48-byte runs) keep that path.
+    // 128-byte line follows with the lane's second pixel)
     if (p.out_f32) {
       const Tile<2> Tw = tile_again2(p);
       const int lr = Tw.lr0 + Tw.ly, w = Tw.w0 + Tw.lx0 + 16 * q;
@@ -1613,10 +1548,15 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
         o[2] = b;
       }
     }
-    if (p.out_u8) {
-      park[q][0][tid] = r; // the pixel's slots now hold its colour
-      park[q][1][tid] = g;
-      park[q][2][tid] = b;
+    if (p.out_u8) { // main.cpp:676-682; three bytes per pixel, 48 consecutive bytes per tile row and pixel q
+      const Tile<2> Tw = tile_again2(p);
+      const int lr = Tw.lr0 + Tw.ly, w = Tw.w0 + Tw.lx0 + 16 * q;
+      if (lr < p.n_local_rows && Tw.h_tile + Tw.ly < p.H && w < p.W) {
+        uint8_t *o = p.out_u8 + ((size_t)lr * p.W + w) * 3;
+        o[0] = quantise_channel(r);
+        o[1] = quantise_channel(g);
+        o[2] = quantise_channel(b);
+      }
     }
   }
   {
@@ -1624,10 +1564,7 @@ __global__ void __launch_bounds__(256, TGRP ? 4 : 5) k_frame(const RenderParams 
     const int tid_e = Te.wave * 64 + Te.lane;
     emit_counters_n(p, tid_e, Te.lane, n_inside, n_hit, n_shadow, Te.lane == 0 ? n_any : 0ull,
                     Te.lane == 0 ? (unsigned long long)n_swept * 64ull : 0ull);
-    if (p.out_u8) {
-      __syncthreads(); // every pixel's colour is in its slot
-      write_tile64(p, Te, tid_e, park, false);
-    }
+
   }
 }
 
