@@ -335,10 +335,17 @@ class Renderer:
             bytes_per_pixel, self._dev_ptr(frame, W * H * bytes_per_pixel)))
 
     def render(self, camera, W, H, *, want_u8=False, shadows=True, face_mode=ESC_FACE_FIXED,
-               fixed_face=0, seed=0, stage=ESC_STAGE_AUTO, px=0, flags=0):
+               fixed_face=0, seed=0, stage=ESC_STAGE_AUTO, px=0, flags=0, out=None):
         """Whole frame into host numpy arrays (synchronous): fp32 (H, W, 3), h = 0 bottom row,
-        and optionally the PPM-quantised bytes."""
-        img = np.zeros((H, W, 3), np.float32)
+        and optionally the PPM-quantised bytes.  `out`: a C-contiguous float32 (H, W, 3) array to
+        render into (a fresh np.zeros of a 4K frame costs more in first-touch page faults than the
+        frame and its copy back together)."""
+        if out is not None:
+            if out.dtype != np.float32 or out.shape != (H, W, 3) or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous float32 array of shape (H, W, 3)")
+            img = out
+        else:
+            img = np.zeros((H, W, 3), np.float32)
         u8 = np.zeros((H, W, 3), np.uint8) if want_u8 else None
         o = _options(shadows, face_mode, fixed_face, seed, stage, px, flags)
         check(self._lib.esc_render_frame_host(

@@ -442,3 +442,6 @@ def test_no_counters_flag_renders_the_same_frame_and_counts_nothing(esc, rendere
         c2 = renderer.counters()
         assert_bit_equal(b, a, f"flags {flags}: without counters")
         assert c1 == c2 and c1["primary_rays"] == 200 * 120, (c1, c2)
+    buf = np.full((120, 200, 3), 7.0, np.float32)  # a host array the caller owns and reuses
+    assert renderer.render(cam, 200, 120, out=buf) is buf
+    assert_bit_equal(buf, a, "render(out=...)")
