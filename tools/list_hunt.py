@@ -1,6 +1,7 @@
 """Developer hunt: random scenes (tests/random_scenes.py), the default frame (tile lists + light lists) against
 the three-level group sweep (lists off) and, every fourth scene, the index-order sweep -- bit for bit.
-python tools/list_hunt.py [n_scenes] [first_seed]"""
+python tools/list_hunt.py [n_scenes] [first_seed] [oracle_every]  (oracle_every k > 0: every k-th scene is
+also rendered by the CPU oracle and compared bit for bit)"""
 import os
 import sys
 
@@ -15,6 +16,8 @@ from random_scenes import random_scene
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+oracle_every = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+checked = 0
 r = esc.Renderer(0)
 off = esc.ESC_RENDER_NO_TILE_LISTS | esc.ESC_RENDER_NO_LIGHT_LISTS
 bad = lit = listed = served = cones = 0
@@ -29,6 +32,10 @@ for seed in range(first, first + n):
     if seed % 4 == 0:
         c = r.render(cam, W, H, flags=esc.ESC_RENDER_INDEX_ORDER)
         nd += int((a.view(np.uint32) != c.view(np.uint32)).any(axis=2).sum())
+    if oracle_every and seed % oracle_every == 0:
+        ref = ol.oracle_render(d, eye, look, W, H, threads=16, vfov=vfov)
+        nd += int((a.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
+        checked += 1
     lit += 1 if a.any() else 0
     listed += 1 if any(s is not None and s["off"] == 0 for s in st[:2]) else 0
     served += 1 if any(s is not None and s["off"] == 0 for s in st[2:]) else 0
@@ -39,4 +46,4 @@ for seed in range(first, first + n):
     if (seed - first) % 100 == 99:
         print(f"... {seed - first + 1} scenes, {bad} differ", flush=True)
 print(f"{n} scenes from seed {first}: {lit} with lit pixels, {listed} with tile lists, {served} with light lists, "
-      f"{cones} with escape entries, {bad} with a difference")
+      f"{cones} with escape entries, {checked} also against the oracle, {bad} with a difference")
